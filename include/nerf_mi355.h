@@ -1,0 +1,143 @@
+/*
+ * nerf_mi355.h -- C ABI of libnerf_mi355.so, the MI355X (gfx950) NeRF volumetric renderer.
+ *
+ * Drop-in boundary for the render hot path of Sahar-E/NeRF-and-DietNeRF.  The reference has no
+ * FFI of its own; its seam is the late-bound Python call `src.UtilsNeuralRadianceField.render_rays`
+ * (src/NeRF.py:180-188).  Each entry point below names the reference function it replaces.
+ * Plain pointers and sizes only: no torch / TensorFlow types cross this boundary.
+ *
+ * Conventions
+ *   - all arrays are C-contiguous fp32 unless stated; rays are (N,4) homogeneous rows exactly as the
+ *     reference passes them (origin w=1, direction w=0); only xyz is read (src/UtilsNRF.py:204).
+ *   - `mem` says where EVERY pointer of that call lives: NERF_MEM_HOST (library stages through its
+ *     own device arena) or NERF_MEM_DEVICE (pointers are used in place on the ctx's stream).
+ *   - every function returns 0 on success, non-zero on error; nerf_last_error() gives the
+ *     thread-local message.  The library never aborts the process and never falls back to a CPU path.
+ *   - a ctx is single-caller (not re-entrant), owns one HIP stream, the device copies of both
+ *     networks' weights and a scratch arena; the caller owns all in/out buffers.
+ *   - calls are synchronous on return for NERF_MEM_HOST; for NERF_MEM_DEVICE they are enqueued on the
+ *     ctx stream and the caller synchronises with nerf_ctx_synchronize() (or its own stream, if it
+ *     installed one with nerf_ctx_set_stream()).
+ */
+#ifndef NERF_MI355_H
+#define NERF_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+
+enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
+enum { NERF_MEM_HOST = 0, NERF_MEM_DEVICE = 1 };
+/* arithmetic of the 256-wide contractions; everything else is always fp32 */
+enum {
+    NERF_PRECISION_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode)      */
+    NERF_PRECISION_F16X3 = 1   /* 3-pass split-fp16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+};
+
+/* Network + frustum description: the 9 net/render keys of src/ConfigurationKeys.py:64-111. */
+typedef struct nerf_config {
+    int32_t n_pos_enc_xyz;    /* n_pos_enc_dim_xyz   (5)   */
+    int32_t n_pos_enc_dir;    /* n_pos_enc_view_dir  (4)   */
+    int32_t n_angles;         /* n_angles_for_model  (2)   */
+    int32_t hidden_dim;       /* hidden_layer_dim    (256) */
+    int32_t last_hidden_dim;  /* last_hidden_layer_dim (128) */
+    float leaky_relu_alpha;   /* leaky_relu_alpha    (0.05) */
+    float near_boundary;      /* NeRF.near_boundary, src/NeRF.py:45 */
+    float far_boundary;       /* NeRF.far_boundary,  src/NeRF.py:46 */
+    int32_t precision;        /* NERF_PRECISION_*    */
+    int32_t device;           /* HIP device ordinal  */
+} nerf_config;
+
+/* Output set of render_rays()/render(); any pointer may be NULL (= not wanted).
+ * Shapes for N rays and S samples of the LAST pass (S = Sc if no fine net, else Sc+Sf). */
+typedef struct nerf_outputs {
+    float* rgb;          /* (N,3)   render_result           src/UtilsNRF.py:114  */
+    float* weights;      /* (N,S)   alpha * cumprod         :113                 */
+    float* cumprod;      /* (N,S)   exclusive transmittance :112                 */
+    float* alpha;        /* (N,S)                           :111                 */
+    float* rgb_samples;  /* (N,S,3) sigmoid(net rgb)        :101                 */
+    float* z;            /* (N,S)   sample depths           src/NeRF.py:132-134  */
+    float* depth;        /* (N)     sum_s w*z               src/ExecutionRun.py:346 (optional 7th) */
+} nerf_outputs;
+
+typedef struct nerf_ctx nerf_ctx;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+/* replaces NeRF.__init__/init_network (src/NeRF.py:27-79): validates cfg, creates stream + arena */
+int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out);
+void nerf_ctx_destroy(nerf_ctx* ctx);
+int nerf_ctx_synchronize(nerf_ctx* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
+ * NERF_STREAM_OWN restores the ctx's own stream */
+#define NERF_STREAM_OWN ((void*)(intptr_t)-1)
+int nerf_ctx_set_stream(nerf_ctx* ctx, void* hip_stream);
+/* change the frustum (near/far) or precision after creation */
+int nerf_ctx_set_bounds(nerf_ctx* ctx, float near_boundary, float far_boundary);
+int nerf_ctx_set_precision(nerf_ctx* ctx, int precision);
+
+/* replaces Keras load_weights / model.get_weights() order (src/ExecutionRun.py:228-231):
+ * `blob` = the 22 tensors of one network, kernel(in,out) row-major then bias, layer order of
+ * src/NeRF.py:319-337 (dense .. dense_10).  HOST pointer.  n_floats must equal nerf_blob_size(). */
+size_t nerf_blob_size(const nerf_config* cfg);
+int nerf_load_weights(nerf_ctx* ctx, int which, const float* blob, size_t n_floats);
+
+/* ---- the functions on the path, one entry each ---------------------- */
+/* get_rays_directions, src/UtilsCV.py:467-499.  c2w row-major (4,4) HOST; dirs (H*W,4). */
+int nerf_get_rays_directions(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int32_t W,
+                             float* dirs, int mem);
+/* get_z_values(near,far,N,1,S)[:,0,:], src/UtilsCV.py:565-581.  u (N,S) uniform draws or NULL
+ * (= on-device Philox keyed by seed and global ray index ray_base+r).  z (N,S). */
+int nerf_get_z_values(nerf_ctx* ctx, int64_t N, int32_t S, const float* u, uint64_t seed,
+                      int64_t ray_base, float* z, int mem);
+/* get_z_vals_from_prob_dist_func, src/UtilsCV.py:502-539.  weights,z (N,S); u (N,Sf) or NULL;
+ * z_new (N,Sf) sorted.  If z_merged != NULL also writes sort(concat(z_new,z)) (N,S+Sf)
+ * (src/NeRF.py:132). */
+int nerf_sample_pdf(nerf_ctx* ctx, const float* weights, const float* z, int64_t N, int32_t S,
+                    int32_t Sf, const float* u, uint64_t seed, int64_t ray_base, float* z_new,
+                    float* z_merged, int mem);
+/* positional_encoding_for_xyz / _for_views, src/UtilsNRF.py:52-85 (standalone, for tests/tools;
+ * the render path computes the encoding in-register inside the MLP kernel). x (M,3). */
+int nerf_positional_encoding(nerf_ctx* ctx, const float* x, int64_t M, int32_t n_enc,
+                             int32_t with_passthrough, float* out, int mem);
+/* model_predict, src/UtilsNRF.py:214-234 + Keras model call src/NeRF.py:316-339.
+ * xyz (M,3), view_dirs (M,3) -> raw (M,4) [r,g,b,sigma]. */
+int nerf_model_predict(nerf_ctx* ctx, int which, const float* xyz, const float* view_dirs,
+                       int64_t M, float* raw, int mem);
+/* ray_marching, src/UtilsNRF.py:88-115.  raw (N,S,4), z (N,S). */
+int nerf_ray_marching(nerf_ctx* ctx, const float* raw, const float* z, int64_t N, int32_t S,
+                      const nerf_outputs* outs, int mem);
+/* render_rays, src/UtilsNRF.py:181-211 (the seam NeRF.render_rays binds, src/NeRF.py:180-188). */
+int nerf_render_rays(nerf_ctx* ctx, int which, const float* rays_orig, const float* rays_dirs,
+                     const float* z, int64_t N, int32_t S, const nerf_outputs* outs, int mem);
+/* NeRF.render, src/NeRF.py:109-134: stratified coarse pass -> inverse-CDF resample -> fine pass on
+ * sort(concat).  Sf == 0 (or no fine weights loaded) = coarse only.  u_coarse (N,Sc), u_fine (N,Sf)
+ * or NULL for on-device Philox(seed, ray_base + r). */
+int nerf_render(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, int64_t N,
+                int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
+                int64_t ray_base, const nerf_outputs* outs, int mem);
+/* NeRF.render_image, src/NeRF.py:190-246, for the ray slab [ray_begin, ray_begin+ray_count) of the
+ * row-major H*W image (ray_count <= 0 = whole image).  Outputs are slab-sized.  batch = rays per
+ * internal pass (0 = library default); results do not depend on it.  u_* index by GLOBAL ray. */
+int nerf_render_image(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int32_t W,
+                      int64_t ray_begin, int64_t ray_count, int64_t batch, int32_t Sc, int32_t Sf,
+                      const float* u_coarse, const float* u_fine, uint64_t seed,
+                      const nerf_outputs* outs, int mem);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* When enabled, every fused PE+MLP kernel launch is bracketed by HIP events on the ctx stream.
+ * nerf_ctx_read_timing synchronises, returns the summed kernel time / launch count / MLP rows
+ * since the last read, and resets the counters. */
+int nerf_ctx_enable_timing(nerf_ctx* ctx, int on);
+int nerf_ctx_read_timing(nerf_ctx* ctx, double* mlp_ms, int64_t* n_launches, int64_t* n_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_MI355_H */

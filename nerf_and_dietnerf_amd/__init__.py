@@ -1,0 +1,17 @@
+"""nerf_and_dietnerf_amd -- MI355X-native drop-in for the NeRF render hot path of
+Sahar-E/NeRF-and-DietNeRF (ray generation, stratified + inverse-CDF sampling, positional encoding,
+coarse/fine MLP forward, alpha compositing) as hand-written HIP kernels behind a C ABI
+(include/nerf_mi355.h).  See DESIGN.md / INTEGRATION.md.
+
+Importing this package does not need a GPU; creating a Context does (there is no CPU fallback).
+"""
+from . import _lib
+from ._lib import (NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FINE, NERF_PRECISION_F16X3,
+                   NERF_PRECISION_FP32)
+from .render import (Context, NeRF, NetHandle, default_context, get_rays_directions, get_size_of_splits,
+                     get_z_vals_from_prob_dist_func, get_z_values, model_predict, positional_encoding_for_views,
+                     positional_encoding_for_xyz, ray_marching, render_rays, split_to_batches)
+from .sharding import gather_slabs, ray_slab, render_image_sharded
+from .weights import blob_size, glorot_blob, layer_shapes
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,86 @@
+// nerf_kernels.h -- internal declarations shared by the HIP translation units of libnerf_mi355.so.
+// gfx950 (MI355X) only.  Nothing here is part of the C ABI (see include/nerf_mi355.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nerf {
+
+// ---- fixed network geometry of the fused kernel (all BASELINE configs) ----
+constexpr int kLx = 5;           // n_pos_enc_dim_xyz
+constexpr int kLd = 4;           // n_pos_enc_view_dir
+constexpr int kHidden = 256;
+constexpr int kLast = 128;
+constexpr int kXyzDim = 3 + 6 * kLx;   // 33
+constexpr int kDirDim = 6 * kLd;       // 24
+
+// ---- weight stream geometry (see DESIGN.md "weight stream") ----
+// A "quad" is the A operand of 4 consecutive MFMA k-steps for one 32-wide output tile:
+// 64 lanes x 4 floats = 1 KiB, lane-linear, read with one ds_read_b128 per lane.
+constexpr int kQuadBytes = 1024;
+constexpr int kChunkQuads = 16;
+constexpr int kChunkBytes = kQuadBytes * kChunkQuads;   // 16 KiB = one LDS ring slot
+constexpr int kRingChunks = 4;
+constexpr int kRingBytes = kChunkBytes * kRingChunks;   // 64 KiB
+
+// quads per output tile for each layer body
+constexpr int kQpuPE = 5;                 // 17 k-steps (15 sin/cos pairs + raw xyz) padded to 20
+constexpr int kQpuHid = 32;               // 128 k-steps
+constexpr int kQpuSkip = kQpuPE + kQpuHid;  // layer 4: [xyz_enc(33), hidden(256)]
+constexpr int kQpuLast = kQpuHid + 3;     // layer 8: [hidden(256), dir_enc(24)] -> 128
+constexpr int kChunksPE = (8 * kQpuPE + 15) / 16;      // 3
+constexpr int kChunksHid = (8 * kQpuHid) / 16;         // 16
+constexpr int kChunksSkip = (8 * kQpuSkip + 15) / 16;  // 19
+constexpr int kChunksLast = (4 * kQpuLast + 15) / 16;  // 9
+constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksLast;  // 127
+constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
+
+// ---- constant region (biases + head weights), floats ----
+constexpr int kConstBias = 0;                       // 8 x 256 hidden-layer biases (layers 0..7)
+constexpr int kConstBias8 = 2048;                   // 128
+constexpr int kConstWrgb = 2176;                    // [3][128]
+constexpr int kConstBHead = 2560;                   // b_r, b_g, b_b, b_sigma
+constexpr int kConstWsigH = 2564;                   // [256]  sigma head, hidden part
+constexpr int kConstWsigD = 2820;                   // [3][2][4] sigma head, dir part (g, half, e)
+constexpr int kConstFloats = 2848;                  // padded to a multiple of 16 B
+constexpr int kConstBytes = kConstFloats * 4;
+
+// LDS carve of the MLP kernel
+constexpr int kLdsRing = 0;
+constexpr int kLdsConst = kRingBytes;
+constexpr int kLdsTotal = kRingBytes + kConstBytes;   // 76,928 B
+
+struct MlpArgs {
+    const float* wstream;   // packed A-operand stream of one network (kStreamBytes)
+    const float* wconst;    // constant region (kConstFloats)
+    const float* in_a;      // mode 0: rays_orig (N,4)   | mode 1: xyz (M,3)
+    const float* in_b;      // mode 0: rays_dirs (N,4)   | mode 1: view_dirs (M,3)
+    const float* z;         // mode 0: (N,S)             | mode 1: unused
+    float* raw;             // (M,4) raw [r,g,b,sigma]
+    long long M;            // number of samples (rows)
+    int S;                  // samples per ray (mode 0)
+    int mode;
+    float alpha;            // LeakyReLU slope
+};
+
+// mlp_fp32.hip
+void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream);
+void mlp_fp32_set_attributes();
+// host-side packing of one network's blob (11 x (kernel(in,out), bias)) into stream + const
+void pack_weights_fp32(const float* blob, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
+
+// aux_kernels.hip
+void launch_raygen(const float* unused, const float c2w_host[16], float fov, int H, int W,
+                   long long ray_begin, long long ray_count, float* orig /*nullable*/, float* dirs,
+                   hipStream_t stream);
+void launch_z_values(float near_b, float far_b, long long N, int S, const float* u, uint64_t seed,
+                     long long ray_base, float* z, hipStream_t stream);
+size_t sample_pdf_lds_bytes(int S, int Sf);
+void launch_sample_pdf(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
+                       uint64_t seed, long long ray_base, float* z_new, float* z_merged,
+                       hipStream_t stream);
+void launch_composite(const float* raw, const float* z, long long N, int S, float* rgb, float* weights,
+                      float* cumprod, float* alpha, float* rgb_samples, float* depth, hipStream_t stream);
+void launch_posenc(const float* x, long long M, int n_enc, int passthrough, float* out, hipStream_t stream);
+
+}  // namespace nerf

@@ -1,0 +1,448 @@
+"""Host-side mirror of the reference's render call surface, over the C ABI of libnerf_mi355.so.
+
+Same names, argument meaning and error behaviour as the reference (paths under /root/reference):
+    NeRF.render / render_image / render_rays / call          src/NeRF.py:96-246
+    render_rays, ray_marching, model_predict,
+    positional_encoding_for_xyz/_for_views,
+    split_to_batches, get_size_of_splits                     src/UtilsNeuralRadianceField.py:17-234
+    get_rays_directions, get_z_values,
+    get_z_vals_from_prob_dist_func                           src/UtilsCV.py:467-581
+
+Arrays may be numpy (host: the library stages them) or torch CUDA tensors (device: used in place on
+torch's current stream); outputs come back in the same kind.  The two random draws the reference
+takes from tf.random.uniform are explicit (``u_coarse``/``u_fine``/``uniform_values``) or come
+from the on-device Philox generator keyed by ``seed`` and the global ray index.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FINE, NERF_PRECISION_F16X3,
+                   NERF_PRECISION_FP32, NerfConfig, NerfOutputs)
+
+# configuration key names (src/ConfigurationKeys.py:64-111)
+N_RENDER_SAMPLES_FINE = "n_render_samples_fine"
+N_RENDER_SAMPLES_COARSE = "n_render_samples_coarse"
+N_POS_ENC_DIM_XYZ = "n_pos_enc_dim_xyz"
+N_POS_ENC_VIEW_DIR = "n_pos_enc_view_dir"
+N_ANGLES_FOR_MODEL = "n_angles_for_model"
+LEAKY_RELU_ALPHA = "leaky_relu_alpha"
+HIDDEN_LAYER_DIM = "hidden_layer_dim"
+LAST_HIDDEN_LAYER_DIM = "last_hidden_layer_dim"
+N_RAYS_IN_BATCH_RENDER = "n_rays_in_batch_render"
+N_RAYS_IN_BATCH_TRAIN = "n_rays_in_batch_train"
+
+N_COORDINATES = 3
+N_COLOR_CHANNELS = 3
+
+_PRECISIONS = {"fp32": NERF_PRECISION_FP32, "f16x3": NERF_PRECISION_F16X3}
+
+
+# --------------------------------------------------------------------------------------------
+# array plumbing: numpy (host) or torch.cuda (device)
+# --------------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class _Arrays:
+    """Decides host/device for one call, keeps converted inputs alive, allocates outputs."""
+
+    def __init__(self, *probe):
+        self.torch = None
+        self.keep = []
+        dev = [p for p in probe if p is not None and _is_torch(p) and p.is_cuda]
+        if dev:
+            import torch
+            self.torch = torch
+            self.device = dev[0].device
+        self.mem = NERF_MEM_DEVICE if self.torch else NERF_MEM_HOST
+
+    def inp(self, x, shape=None) -> Optional[int]:
+        if x is None:
+            return None
+        if self.torch:
+            t = x if _is_torch(x) else self.torch.as_tensor(np.asarray(x, np.float32))
+            t = t.to(device=self.device, dtype=self.torch.float32).contiguous()
+            if shape is not None and tuple(t.shape) != tuple(shape):
+                raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+            self.keep.append(t)
+            return t.data_ptr()
+        if _is_torch(x):
+            x = x.detach().cpu().numpy()
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+        self.keep.append(a)
+        return a.ctypes.data
+
+    def out(self, shape):
+        if self.torch:
+            t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.device)
+            self.keep.append(t)
+            return t, t.data_ptr()
+        a = np.empty(tuple(shape), np.float32)
+        self.keep.append(a)
+        return a, a.ctypes.data
+
+
+class Context:
+    """One nerf_ctx: one GPU, one stream, both networks' weights, a scratch arena."""
+
+    def __init__(self, *, n_pos_enc_xyz=5, n_pos_enc_dir=4, n_angles=2, hidden_dim=256, last_hidden_dim=128,
+                 leaky_relu_alpha=0.05, near=2.0, far=6.0, precision="fp32", device=0):
+        self.lib = _lib.load()
+        if n_angles not in (0, 1, 2):
+            raise Exception(f"{N_ANGLES_FOR_MODEL} should be 1 or 2.")   # src/UtilsCV.py:138
+        self.cfg = NerfConfig(n_pos_enc_xyz, n_pos_enc_dir, n_angles, hidden_dim, last_hidden_dim,
+                              leaky_relu_alpha, near, far, _PRECISIONS[precision], device)
+        h = C.c_void_p()
+        _lib.check(self.lib.nerf_ctx_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.loaded = [False, False]
+        self._stream = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nerf_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def blob_size(self) -> int:
+        return int(self.lib.nerf_blob_size(C.byref(self.cfg)))
+
+    def load_weights(self, which: int, weights) -> None:
+        """``weights``: flat fp32 blob, or the Keras ``model.get_weights()`` list (22 arrays,
+        kernel(in,out) then bias, layers in creation order src/NeRF.py:319-337)."""
+        if isinstance(weights, (list, tuple)):
+            blob = np.concatenate([np.asarray(w, np.float32).ravel() for w in weights])
+        else:
+            blob = np.ascontiguousarray(np.asarray(weights, np.float32).ravel())
+        _lib.check(self.lib.nerf_load_weights(self.h, which, blob.ctypes.data, blob.size))
+        self.loaded[which] = True
+
+    def set_bounds(self, near: float, far: float) -> None:
+        _lib.check(self.lib.nerf_ctx_set_bounds(self.h, near, far))
+        self.cfg.near_boundary, self.cfg.far_boundary = near, far
+
+    def synchronize(self) -> None:
+        _lib.check(self.lib.nerf_ctx_synchronize(self.h))
+
+    def use_torch_stream(self) -> None:
+        """Enqueue on torch's current stream, so torch events/ops order with the kernels."""
+        import torch
+        cur = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.nerf_ctx_set_stream(self.h, C.c_void_p(cur)))
+        self._stream = cur
+
+    def enable_timing(self, on: bool = True) -> None:
+        _lib.check(self.lib.nerf_ctx_enable_timing(self.h, int(on)))
+
+    def read_timing(self) -> Tuple[float, int, int]:
+        ms, n, rows = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib.nerf_ctx_read_timing(self.h, C.byref(ms), C.byref(n), C.byref(rows)))
+        return ms.value, n.value, rows.value
+
+    def _arrays(self, *probe) -> "_Arrays":
+        """Device-resident arguments => run on torch's current stream (ordering with torch ops)."""
+        arr = _Arrays(*probe)
+        if arr.torch is not None:
+            cur = arr.torch.cuda.current_stream(arr.device).cuda_stream
+            if cur != self._stream:
+                _lib.check(self.lib.nerf_ctx_set_stream(self.h, C.c_void_p(cur)))
+                self._stream = cur
+        return arr
+
+    # ---- path functions ----
+    def _outputs(self, arr: _Arrays, n: int, s: int, want_depth: bool, lead: Tuple[int, ...] = None):
+        lead = (n,) if lead is None else lead
+        rgb, p0 = arr.out(lead + (3,))
+        w, p1 = arr.out(lead + (s,))
+        t, p2 = arr.out(lead + (s,))
+        a, p3 = arr.out(lead + (s,))
+        c, p4 = arr.out(lead + (s, 3))
+        z, p5 = arr.out(lead + (s,))
+        d, p6 = arr.out(lead) if want_depth else (None, None)
+        o = NerfOutputs(p0, p1, p2, p3, p4, p5, p6)
+        return o, (rgb, w, t, a, c, z, d)
+
+    def get_rays_directions(self, height, width, field_of_view, c2w):
+        arr = self._arrays(c2w if _is_torch(c2w) else None)
+        c2w_h = np.ascontiguousarray(c2w.detach().cpu().numpy() if _is_torch(c2w) else c2w, dtype=np.float32)
+        if c2w_h.shape != (4, 4):
+            raise ValueError("c2w must be (4,4)")
+        out, p = arr.out((height, width, 4))
+        _lib.check(self.lib.nerf_get_rays_directions(self.h, c2w_h.ctypes.data, float(field_of_view), height, width,
+                                                     p, arr.mem))
+        return out
+
+    def get_z_values(self, z_start, z_end, height, width, n_samples, uniform_values=None, seed=0, ray_base=0):
+        """(height, width, n_samples) like src/UtilsCV.py:565-581; rays are numbered row-major."""
+        if (z_start, z_end) != (self.cfg.near_boundary, self.cfg.far_boundary):
+            self.set_bounds(float(z_start), float(z_end))
+        arr = self._arrays(uniform_values)
+        n = int(height) * int(width)
+        pu = arr.inp(None if uniform_values is None else _reshape(uniform_values, (n, n_samples)), (n, n_samples))
+        out, p = arr.out((height, width, n_samples))
+        _lib.check(self.lib.nerf_get_z_values(self.h, n, n_samples, pu, seed, ray_base, p, arr.mem))
+        return out
+
+    def get_z_vals_from_prob_dist_func(self, weights, z_values, num_new_z_values, uniform_values=None, seed=0,
+                                       ray_base=0, return_merged=False):
+        arr = self._arrays(weights, z_values, uniform_values)
+        n, s = tuple(weights.shape)
+        pw, pz = arr.inp(weights, (n, s)), arr.inp(z_values, (n, s))
+        pu = arr.inp(uniform_values, (n, num_new_z_values))
+        zn, pn = arr.out((n, num_new_z_values))
+        zm, pm = arr.out((n, s + num_new_z_values)) if return_merged else (None, None)
+        _lib.check(self.lib.nerf_sample_pdf(self.h, pw, pz, n, s, num_new_z_values, pu, seed, ray_base, pn, pm,
+                                            arr.mem))
+        return (zn, zm) if return_merged else zn
+
+    def positional_encoding(self, x, n_positional_encoding, passthrough):
+        arr = self._arrays(x)
+        m = int(x.shape[0])
+        px = arr.inp(x, (m, 3))
+        per = 3 * ((1 if passthrough else 0) + 2 * n_positional_encoding)
+        out, p = arr.out((m, per))
+        _lib.check(self.lib.nerf_positional_encoding(self.h, px, m, n_positional_encoding, int(passthrough), p,
+                                                     arr.mem))
+        return out
+
+    def model_predict(self, which, xyz, view_dirs):
+        arr = self._arrays(xyz, view_dirs)
+        m = int(xyz.shape[0])
+        px, pv = arr.inp(xyz, (m, 3)), arr.inp(view_dirs, (m, 3))
+        out, p = arr.out((m, 4))
+        _lib.check(self.lib.nerf_model_predict(self.h, which, px, pv, m, p, arr.mem))
+        return out
+
+    def ray_marching(self, model_output, z_values):
+        arr = self._arrays(model_output, z_values)
+        n, s = tuple(z_values.shape)
+        pr, pz = arr.inp(model_output, (n, s, 4)), arr.inp(z_values, (n, s))
+        o, res = self._outputs(arr, n, s, False)
+        o.z = None
+        _lib.check(self.lib.nerf_ray_marching(self.h, pr, pz, n, s, C.byref(o), arr.mem))
+        return res[:5]
+
+    def render_rays(self, which, rays_orig, rays_dirs, z_values):
+        arr = self._arrays(rays_orig, rays_dirs, z_values)
+        n, s = tuple(z_values.shape)
+        po, pd, pz = arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4)), arr.inp(z_values, (n, s))
+        o, res = self._outputs(arr, n, s, False)
+        o.z = None
+        _lib.check(self.lib.nerf_render_rays(self.h, which, po, pd, pz, n, s, C.byref(o), arr.mem))
+        return res[:5]
+
+    def render(self, rays_orig, rays_dirs, n_c, n_f, u_coarse=None, u_fine=None, seed=0, ray_base=0,
+               want_depth=False):
+        arr = self._arrays(rays_orig, rays_dirs, u_coarse, u_fine)
+        n = int(rays_orig.shape[0])
+        fine = n_f > 0 and self.loaded[NERF_NET_FINE]
+        s = n_c + n_f if fine else n_c
+        po, pd = arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4))
+        puc = arr.inp(u_coarse, (n, n_c))
+        puf = arr.inp(u_fine, (n, n_f)) if fine else None
+        o, res = self._outputs(arr, n, s, want_depth)
+        _lib.check(self.lib.nerf_render(self.h, po, pd, n, n_c, n_f if fine else 0, puc, puf, seed, ray_base,
+                                        C.byref(o), arr.mem))
+        return res if want_depth else res[:6]
+
+    def render_image(self, c2w, fov, h, w, batch, n_c, n_f, u_coarse=None, u_fine=None, seed=0, ray_begin=0,
+                     ray_count=0, want_depth=False, device_out=False, rgb_only=False):
+        """Whole image (ray_count=0) -> outputs shaped (h,w,...); a slab -> outputs shaped (ray_count,...)."""
+        arr = self._arrays(u_coarse, u_fine)
+        if device_out and arr.torch is None:
+            import torch
+            arr = self._arrays(torch.empty(1, device=torch.device("cuda", self.cfg.device)))
+        c2w_h = np.ascontiguousarray(c2w.detach().cpu().numpy() if _is_torch(c2w) else c2w, dtype=np.float32)
+        if c2w_h.shape != (4, 4):
+            raise ValueError("c2w must be (4,4)")
+        total = h * w
+        fine = n_f > 0 and self.loaded[NERF_NET_FINE]
+        s = n_c + n_f if fine else n_c
+        puc = arr.inp(u_coarse, (total, n_c))
+        puf = arr.inp(u_fine, (total, n_f)) if fine else None
+        whole = ray_count <= 0
+        n = total if whole else ray_count
+        lead = (h, w) if whole else (n,)
+        if rgb_only:
+            rgb, p0 = arr.out(lead + (3,))
+            d, p6 = arr.out(lead) if want_depth else (None, None)
+            o, res = NerfOutputs(p0, None, None, None, None, None, p6), (rgb, None, None, None, None, None, d)
+        else:
+            o, res = self._outputs(arr, n, s, want_depth, lead)
+        _lib.check(self.lib.nerf_render_image(self.h, c2w_h.ctypes.data, float(fov), h, w, 0 if whole else ray_begin,
+                                              0 if whole else ray_count, batch or 0, n_c, n_f if fine else 0, puc,
+                                              puf, seed, C.byref(o), arr.mem))
+        return res if want_depth else res[:6]
+
+
+def _reshape(x, shape):
+    return x.reshape(shape)
+
+
+class NetHandle:
+    """Stands in for the Keras ``model`` argument of render_rays / model_predict."""
+
+    def __init__(self, ctx: Context, which: int):
+        self.ctx, self.which = ctx, which
+
+
+class NeRF:
+    """Mirror of the reference model class (src/NeRF.py:22-246), forward/render path only."""
+
+    def __init__(self, net_config: Dict, render_config: Dict, near_boundary: float, far_boundary: float,
+                 device: int = 0, precision: str = "fp32"):
+        self.ctx = Context(n_pos_enc_xyz=net_config[N_POS_ENC_DIM_XYZ], n_pos_enc_dir=net_config[N_POS_ENC_VIEW_DIR],
+                           n_angles=net_config[N_ANGLES_FOR_MODEL], hidden_dim=net_config[HIDDEN_LAYER_DIM],
+                           last_hidden_dim=net_config[LAST_HIDDEN_LAYER_DIM],
+                           leaky_relu_alpha=net_config[LEAKY_RELU_ALPHA], near=near_boundary, far=far_boundary,
+                           precision=precision, device=device)
+        self.model_coarse = NetHandle(self.ctx, NERF_NET_COARSE)
+        self.model_fine = NetHandle(self.ctx, NERF_NET_FINE) if render_config[N_RENDER_SAMPLES_FINE] > 0 else None
+        self.batch_size_render = net_config.get(N_RAYS_IN_BATCH_RENDER, 4096)
+        self.batch_size_train = net_config.get(N_RAYS_IN_BATCH_TRAIN, 4096)
+        self.near_boundary, self.far_boundary = near_boundary, far_boundary
+        self.n_render_samples_coarse = render_config[N_RENDER_SAMPLES_COARSE]
+        self.n_render_samples_fine = render_config[N_RENDER_SAMPLES_FINE]
+        self.n_pos_enc_dim_xyz = net_config[N_POS_ENC_DIM_XYZ]
+        self.n_pos_enc_view_dir = net_config[N_POS_ENC_VIEW_DIR]
+        self.n_angles_for_model = net_config[N_ANGLES_FOR_MODEL]
+        self.seed = 0
+
+    def set_weights(self, coarse, fine=None) -> None:
+        self._blobs = [coarse, fine]
+        self.ctx.load_weights(NERF_NET_COARSE, coarse)
+        if fine is not None and self.model_fine is not None:
+            self.ctx.load_weights(NERF_NET_FINE, fine)
+
+    def call(self, inputs, training=None, mask=None):
+        rays_orig, rays_dirs = inputs
+        return self.render(rays_orig, rays_dirs)[0]
+
+    __call__ = call
+
+    def render(self, rays_orig, rays_dirs, n_render_samples_c=None, n_render_samples_f=None, *, u_coarse=None,
+               u_fine=None, seed=None, ray_base=0):
+        n_c = n_render_samples_c if n_render_samples_c else self.n_render_samples_coarse
+        n_f = 0
+        if self.model_fine:
+            n_f = n_render_samples_f if n_render_samples_f else self.n_render_samples_fine
+        return self.ctx.render(rays_orig, rays_dirs, n_c, n_f, u_coarse, u_fine,
+                               self.seed if seed is None else seed, ray_base)
+
+    def render_rays(self, model: NetHandle, rays_orig, rays_dirs, z):
+        return render_rays(model, rays_orig, rays_dirs, z, self.n_pos_enc_dim_xyz, self.n_pos_enc_view_dir,
+                           self.n_angles_for_model)
+
+    def render_image(self, c2w, fov, h, w, batch_size_input=None, n_render_samples_c=None, n_render_samples_f=None,
+                     *, u_coarse=None, u_fine=None, seed=None, **kw):
+        batch = batch_size_input if batch_size_input else self.batch_size_render
+        assert batch > 0                                           # src/UtilsNRF.py:25
+        n_c = n_render_samples_c if n_render_samples_c else self.n_render_samples_coarse
+        n_f = 0
+        if self.model_fine:
+            n_f = n_render_samples_f if n_render_samples_f else self.n_render_samples_fine
+        return self.ctx.render_image(c2w, fov, h, w, batch, n_c, n_f, u_coarse, u_fine,
+                                     self.seed if seed is None else seed, **kw)
+
+
+# --------------------------------------------------------------------------------------------
+# free functions with the reference's signatures
+# --------------------------------------------------------------------------------------------
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def render_rays(model: NetHandle, rays_orig, rays_dirs, z_values, n_pos_enc_for_xyz: int, n_pos_enc_for_angles: int,
+                n_angles_for_model: int):
+    """src/UtilsNeuralRadianceField.py:181-211 -> (render_result, weights, cumprod, alpha, rgb)."""
+    cfg = model.ctx.cfg
+    if n_angles_for_model not in (1, 2):
+        raise Exception(f"{N_ANGLES_FOR_MODEL} should be 1 or 2.")   # src/UtilsCV.py:138
+    if (n_pos_enc_for_xyz, n_pos_enc_for_angles, n_angles_for_model) != (cfg.n_pos_enc_xyz, cfg.n_pos_enc_dir,
+                                                                         cfg.n_angles):
+        raise ValueError("encoding arguments do not match the network this model handle was built with")
+    return model.ctx.render_rays(model.which, rays_orig, rays_dirs, z_values)
+
+
+def model_predict(model: NetHandle, n_enc_phi_theta: int, n_pos_enc_for_xyz: int, xyz, view_dirs=None):
+    """src/UtilsNeuralRadianceField.py:214-234 -> (M,4) raw (R,G,B,Sigma)."""
+    if view_dirs is None:
+        raise NotImplementedError("n_angles_for_model == 0 network is not built yet")
+    return model.ctx.model_predict(model.which, xyz, view_dirs)
+
+
+def ray_marching(model_output, z_values, ctx: Optional[Context] = None):
+    """src/UtilsNeuralRadianceField.py:88-115."""
+    return (ctx or default_context()).ray_marching(model_output, z_values)
+
+
+def positional_encoding_for_xyz(xyz, n_positional_encoding: int, ctx: Optional[Context] = None):
+    """src/UtilsNeuralRadianceField.py:68-85."""
+    if n_positional_encoding == 0:
+        return xyz.reshape(xyz.shape[0], -1)
+    return (ctx or default_context()).positional_encoding(xyz, n_positional_encoding, True)
+
+
+def positional_encoding_for_views(x, n_positional_encoding: int, ctx: Optional[Context] = None):
+    """src/UtilsNeuralRadianceField.py:52-65 (3-component view directions)."""
+    return (ctx or default_context()).positional_encoding(x, n_positional_encoding, False)
+
+
+def get_rays_directions(height, width, field_of_view, c2w, ctx: Optional[Context] = None):
+    """src/UtilsCV.py:467-499 -> (H,W,4)."""
+    return (ctx or default_context()).get_rays_directions(height, width, field_of_view, c2w)
+
+
+def get_z_values(z_start, z_end, height, width, n_samples, uniform_values=None, seed=0,
+                 ctx: Optional[Context] = None):
+    """src/UtilsCV.py:565-581 -> (height, width, n_samples)."""
+    return (ctx or default_context()).get_z_values(z_start, z_end, height, width, n_samples, uniform_values, seed)
+
+
+def get_z_vals_from_prob_dist_func(weights, z_values, num_new_z_values, uniform_values=None, seed=0,
+                                   ctx: Optional[Context] = None):
+    """src/UtilsCV.py:502-539 -> sorted (N, num_new_z_values)."""
+    return (ctx or default_context()).get_z_vals_from_prob_dist_func(weights, z_values, num_new_z_values,
+                                                                   uniform_values, seed)
+
+
+def get_size_of_splits(batch_size: int, total_size: int) -> List[int]:
+    """src/UtilsNeuralRadianceField.py:32-49 (host logic: defines launch granularity only)."""
+    n_full_batches = total_size // batch_size
+    if n_full_batches == 0:
+        return [total_size]
+    if total_size % batch_size != 0:
+        return [batch_size] * n_full_batches + [-1]
+    return [batch_size] * n_full_batches
+
+
+def split_to_batches(to_split, batch_size):
+    """src/UtilsNeuralRadianceField.py:17-29."""
+    assert batch_size > 0
+    total = to_split.shape[0]
+    out, off = [], 0
+    for s in get_size_of_splits(batch_size, total):
+        s = total - off if s == -1 else s
+        out.append(to_split[off:off + s])
+        off += s
+    return out

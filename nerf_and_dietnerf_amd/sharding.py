@@ -1,0 +1,50 @@
+"""Ray sharding for multi-GPU rendering: one process per GPU, rays of independent pixels split into
+contiguous row-major slabs, weights replicated, ONE all-gather per requested output (RCCL over xGMI
+when the backend is nccl; gloo on CPU in tests).  The reference has no distributed layer
+(SURVEY.md section 8e); this is the build's addition around NeRF.render_image (src/NeRF.py:190-246).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def ray_slab(total_rays: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous slab [begin, begin+count) of rank ``rank``: equal slabs of ceil(total/world) rays,
+    the last ranks may get fewer (or zero).  Equal-sized slabs keep the gather a plain all_gather."""
+    per = -(-total_rays // world_size)
+    begin = min(rank * per, total_rays)
+    return begin, max(0, min(per, total_rays - begin))
+
+
+def gather_slabs(local, total_rays: int, group=None):
+    """all_gather equal-sized (padded) slabs of a per-ray tensor and trim to ``total_rays`` rows."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = -(-total_rays // world)
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out[:total_rays]
+
+
+def render_image_sharded(model, c2w, fov, h, w, group=None, rgb_only=True, **kw):
+    """Every rank renders its slab of the image with ``model`` (a nerf_and_dietnerf_amd.NeRF on this
+    rank's GPU) and all ranks receive the assembled (h,w,...) outputs."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    total = h * w
+    begin, count = ray_slab(total, rank, world)
+    outs = model.render_image(c2w, fov, h, w, ray_begin=begin, ray_count=max(count, 1), device_out=True,
+                              rgb_only=rgb_only, **kw)
+    res = []
+    for o in outs:
+        if o is None:
+            res.append(None)
+            continue
+        o = o[:count]
+        full = gather_slabs(o, total, group)
+        res.append(full.reshape((h, w) + tuple(full.shape[1:])))
+    return tuple(res)
