@@ -71,6 +71,13 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C nerf_and_dietnerf_amd/csrc). "
             "nerf_and_dietnerf_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if it were loaded
+    # AFTER the system copy this library links to, the process would hold two runtimes and the second
+    # would find no GPU.  Importing torch first makes its copy satisfy our DT_NEEDED (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

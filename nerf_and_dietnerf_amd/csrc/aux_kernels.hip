@@ -56,7 +56,8 @@ void launch_raygen(const float*, const float c2w_host[16], float fov, int H, int
     if (ray_count <= 0) return;
     RaygenArgs a;
     for (int i = 0; i < 16; ++i) a.c[i] = c2w_host[i];
-    a.tan_half = tanf(fov * 0.5f);   // tf.tan(field_of_view / 2) evaluated in fp32 (UtilsCV.py:488)
+    // tf.tan(field_of_view / 2) (UtilsCV.py:488): tan of fp32(fov/2), evaluated in double and rounded once
+    a.tan_half = (float)tan((double)(fov * 0.5f));
     a.H = H; a.W = W; a.ray_begin = ray_begin; a.ray_count = ray_count; a.orig = orig; a.dirs = dirs;
     const int bs = 256;
     hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((ray_count + bs - 1) / bs)), dim3(bs), 0, stream, a);

@@ -142,7 +142,8 @@ def get_rays_directions(height: int, width: int, field_of_view: float, c2w: np.n
     y_ndc = yr / F32(height)
     x_ss = F32(2) * x_ndc - F32(1)                           # :485-486
     y_ss = F32(1) - F32(2) * y_ndc
-    tan_half = np.tan(F32(field_of_view / 2))                # :488 (fp32 tan of fp32(fov/2))
+    # :488 tan of fp32(fov/2); evaluated in double and rounded once so every libm agrees on the bits
+    tan_half = F32(math.tan(float(F32(field_of_view / 2))))
     xc = (x_ss * tan_half)[None, :]                          # :489-490
     yc = (y_ss * tan_half)[:, None]
     xc, yc = np.broadcast_arrays(xc, yc)
