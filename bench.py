@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the NeRF render hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+One "step" = one pass of the hot path over one synthetic frame: 256x256 rays, 64 coarse + 128 fine
+samples (ray generation -> stratified z -> coarse PE+MLP -> composite -> inverse-CDF resample ->
+fine PE+MLP on 192 sorted samples -> composite -> RGB), inputs resident in HBM (rays are generated on
+device; weights uploaded before the timed region).  With N > 1 the frame's rays are sharded into N
+contiguous slabs (one process per GPU) and ONE all-gather (RCCL over xGMI) assembles the RGB image on
+every rank inside the timed region: strong scaling of the named config.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (fused PE+MLP, MFMA-bound) from
+HIP events recorded on the kernel's own stream inside the timed region; `cpu_baseline` times the CPU
+oracle (numpy/OpenBLAS restatement of the reference algorithm -- NOT TensorFlow, which is not
+installable here) on a bounded sample of the same workload on the host cores of rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOPS_PER_ROW = 2 * 512152          # GEMM MACs per sample x 2
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak per dtype fed to MFMA
+H = W = 256
+SC, SF = 64, 128
+NEAR, FAR, FOV = 2.0 / 3.0, 5.0 / 3.0, 0.6911112
+
+
+def sphere_matrix(radius, x_rot, y_rot, z_rot):
+    """get_sphere_matrix semantics (src/UtilsCV.py:101-121), restated: Rz Ry Rx T."""
+    xr, yr, zr = np.deg2rad([x_rot, y_rot, z_rot])
+    t = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], dtype=np.float64)
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(xr), -np.sin(xr), 0], [0, np.sin(xr), np.cos(xr), 0], [0, 0, 0, 1]])
+    ry = np.array([[np.cos(yr), 0, -np.sin(yr), 0], [0, 1, 0, 0], [np.sin(yr), 0, np.cos(yr), 0], [0, 0, 0, 1]])
+    rz = np.array([[np.cos(zr), -np.sin(zr), 0, 0], [np.sin(zr), np.cos(zr), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    return (rz @ (ry @ (rx @ t))).astype(np.float32)
+
+
+def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
+    """Oracle ("port") on the host cores, on a bounded sample of the same frame."""
+    from oracle import nerf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    coarse, fine = O.unpack_blob(blob_c), O.unpack_blob(blob_f)
+    dirs = O.get_rays_directions(H, W, FOV, c2w).reshape(-1, 4)
+    orig = np.broadcast_to(c2w[:, 3], dirs.shape).astype(np.float32)
+
+    def run(n):
+        pick = np.linspace(0, H * W - 1, n).astype(np.int64)
+        uc = O.philox_uniform(0, pick.astype(np.uint64), SC, 0)
+        uf = O.philox_uniform(0, pick.astype(np.uint64), SF, 1)
+        t0 = time.perf_counter()
+        O.render(coarse, fine, orig[pick], dirs[pick], NEAR, FAR, uc, uf)
+        return time.perf_counter() - t0
+
+    t_small = run(256)                                   # calibration (also warms BLAS threads)
+    n = int(min(16384, max(512, 256 * seconds_budget / max(t_small, 1e-3))))
+    n = (n // 256) * 256
+    t = run(n)
+    return {"value": n / t, "unit": "rays/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} rays of the same 256x256 frame (64+128 samples), numpy fp32 + OpenBLAS, "
+                      f"{t:.1f} s; CPU restatement of the reference algorithm (not TensorFlow)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import nerf_and_dietnerf_amd as N
+
+    blob_c, blob_f = N.glorot_blob(0), N.glorot_blob(1)       # random-init weights of the reference architecture
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
+               "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
+    model = N.NeRF(net_cfg, {"n_render_samples_coarse": SC, "n_render_samples_fine": SF}, NEAR, FAR,
+                   device=local_rank, precision=args.precision)
+    model.set_weights(blob_c, blob_f)
+    model.ctx.use_torch_stream()
+    c2w = sphere_matrix(1.0, -30.0, 45.0, 0.0)
+    total = H * W
+    begin, count = N.ray_slab(total, rank, world)
+
+    def step(seed):
+        # whole-slab batch (the library's default); results do not depend on the batch size
+        rgb = model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=seed, ray_begin=begin,
+                                 ray_count=count, device_out=True, rgb_only=True)[0]
+        if world > 1:
+            rgb = N.gather_slabs(rgb, total)
+        return rgb
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        img = step(i)
+    sync()
+    model.ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    mlp_ms, n_launch, n_rows = model.ctx.read_timing()
+    model.ctx.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(img).all()) and tuple(img.shape[-1:]) == (3,)
+
+    if rank == 0:
+        value = total * args.steps / elapsed
+        dtype = "f32" if args.precision == "fp32" else "f16x3"
+        ach = (n_rows * FLOPS_PER_ROW) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(dtype)
+        except Exception:
+            pass
+        out = {
+            "metric": "rays/sec (coarse+fine) at 256x256, 64 coarse + 128 fine samples",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic (random-init Glorot weights, sphere pose, "
+                                                          "on-device Philox draws)",
+            "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine, fp32 (BASELINE configs[1])",
+                       "rays_per_step": total, "mlp_rows_per_ray": SC + SC + SF,
+                       "parallelism": f"ray-sharded x{world}, one all-gather of RGB per frame"},
+            "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel (fused PE + 11-layer MLP)",
+                         "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": ach / PEAK_TFLOPS[dtype], "traffic": traffic,
+                         "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),
+                         "flops_per_row": FLOPS_PER_ROW, "rows": int(n_rows)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnerf_mi355.so")
+# NERF_MI355_LIB: developer override to load a diagnostic build of the same ABI
+LIB_PATH = os.environ.get("NERF_MI355_LIB") or os.path.join(_HERE, "lib", "libnerf_mi355.so")
 
 NERF_NET_COARSE, NERF_NET_FINE = 0, 1
 NERF_MEM_HOST, NERF_MEM_DEVICE = 0, 1

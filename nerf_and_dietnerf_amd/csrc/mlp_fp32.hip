@@ -40,36 +40,78 @@ __device__ __forceinline__ f32x4 lds_read4(uint32_t byte_off) {
 }
 
 struct Pipe {
-    int ck;        // chunk being consumed (monotonic; ring position = ck & 3)
-    int src_next;  // next chunk index of the cyclic weight stream to DMA (0..kStreamChunks-1)
+    int ck;             // chunk being consumed (monotonic; ring position = ck % kRingChunks)
+    int src_next;       // next chunk index of the cyclic weight stream to DMA (0..kStreamChunks-1)
+    const char* wbase;  // packed weight stream (wave-uniform)
+    uint32_t voff;      // this lane's byte offset inside a chunk: wave*4 KiB + lane*16
+    uint32_t wave_lds;  // wave*4 KiB
+    // the chunk whose 4 pieces are being dealt out after the latest sync
+    const char* cur_src;
+    uint32_t cur_dst;
 };
 
-// Issue this wave's 4 KiB share of one 16 KiB chunk: 4 x global_load_lds_dwordx4 (1 KiB each).
-__device__ __forceinline__ void dma_issue(const char* wsrc_lane, int src_chunk, int ring_pos, int wave) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const char* g = wsrc_lane + (size_t)src_chunk * kChunkBytes;
-    char* l = smem + kLdsRing + ring_pos * kChunkBytes + wave * (4 * kQuadBytes);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_global_load_lds((const GLB_AS void*)(g + j * kQuadBytes),
-                                         (LDS_AS void*)(l + j * kQuadBytes), 16, 0, 0);
-    }
+// One LDS-DMA piece: global_load_lds_dwordx4 moves 1 KiB (64 lanes x 16 B) from
+// sbase + voff (per-lane byte offset) to LDS at m0_dst + lane*16.  A wave's share of a 16 KiB chunk
+// is 4 pieces.  Inline asm on purpose: with the builtin form hipcc (ROCm 7.2) treats every later
+// ds_read as possibly aliasing the in-flight DMA and degrades all its LDS waits to lgkmcnt(0); hidden
+// from the compiler, its ds_read waits stay counted and the DMA is ordered by our own vmcnt/barrier.
+// Each piece costs ~60 issue cycles, about one 64-cycle MFMA: pieces are dealt out one per MFMA gap
+// (4 in a row after the barrier cost ~170 idle MFMA cycles per chunk, measured).
+__device__ __forceinline__ void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
 }
 
 // Mid-chunk synchronisation point of chunk p.ck:
-//   vmcnt(4): this wave's share of chunk ck+1 has landed (only chunk ck+2's 4 DMAs may be pending);
+//   vmcnt(4*(R-3)): this wave's share of chunk ck+1 has landed (only the 4 DMAs each of chunks
+//                ck+2 .. ck+R-2 may still be pending; R = kRingChunks);
 //   lgkmcnt(8): every ds_read of chunk ck-1 has returned (at most this chunk's first 8 pending);
-//   barrier:  => all waves' shares of ck+1 are visible, and ring slot (ck-1)&3 is free for reuse.
-// Then issue chunk ck+3 into that free slot.
-__device__ __forceinline__ void pipe_sync(Pipe& p, const char* wsrc_lane, int wave) {
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+//   barrier:  => all waves' shares of ck+1 are visible, and ring slot (ck-1)%R is free for reuse.
+// Then issue chunk ck+R-1 into that free slot.
+__device__ __forceinline__ void pipe_piece(Pipe& p, int j) {
+#if !(defined(NERF_DIAG) && NERF_DIAG == 2)
+    dma_piece(p.cur_src, p.voff + j * kQuadBytes, p.cur_dst + j * kQuadBytes);
+#endif
+}
+
+__device__ __forceinline__ void pipe_sync(Pipe& p, bool all_pieces) {
+#if defined(NERF_DIAG) && NERF_DIAG == 2   // timing-only diagnostic: no wait, no barrier, no DMA
     asm volatile("" ::: "memory");
-    dma_issue(wsrc_lane, p.src_next, (p.ck + 3) & 3, wave);
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(4 * (kRingChunks - 3)) : "memory");
+#if !(defined(NERF_DIAG) && NERF_DIAG == 1)   // NERF_DIAG 1: timing-only, no barrier
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+#endif
+    p.cur_src = p.wbase + (size_t)p.src_next * kChunkBytes;
+    p.cur_dst = kLdsRing + ((p.ck + kRingChunks - 1) & (kRingChunks - 1)) * kChunkBytes + p.wave_lds;
     p.src_next = (p.src_next + 1 == kStreamChunks) ? 0 : p.src_next + 1;
+    pipe_piece(p, 0);
+    if (all_pieces) { pipe_piece(p, 1); pipe_piece(p, 2); pipe_piece(p, 3); }
 }
 
 enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
+
+#ifdef NERF_STAMPS   // diagnostic build only: per-phase cycle sums of wave 0 of workgroup 0
+__device__ unsigned long long g_stamps[16];
+#define STAMP(var)                                                      \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
 
 // One dense layer, u-outer: for each 32-wide output tile run the whole K chain into one accumulator.
 //   BODY_PE   : B = xpe                      -> xin   (layer 0)
@@ -86,95 +128,142 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int BODY>
-__device__ __forceinline__ void layer_body(Pipe& p, const char* wsrc_lane, int wave, uint32_t lane16,
+__device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
                                            uint32_t cb_h, int bias_off_bytes, float alpha,
-                                           float (&xin)[128], float (&xnext)[112], const float (&xpe)[17],
+                                           float (&xin)[128], float (&xnext)[96], const float (&xpe)[17],
                                            const float (&xdir)[12], float (&xc)[64]) {
-    constexpr int NU = BODY == BODY_LAST ? 4 : 8;
+    // Output tiles are processed in PAIRS (u = 2P, 2P+1): the two accumulator chains alternate MFMA by
+    // MFMA, so a dependent v_mfma_f32_32x32x2_f32 is never issued back to back on one accumulator,
+    // and both chains share every B operand.  Stream order per pair: quad(2P,q), quad(2P+1,q), q++.
+    constexpr int NP = BODY == BODY_LAST ? 2 : 4;
     constexpr int QPU = BODY == BODY_PE ? kQpuPE : BODY == BODY_HID ? kQpuHid
                         : BODY == BODY_SKIP ? kQpuSkip : kQpuLast;
-    constexpr int NQ = NU * QPU;
-    f32x16 acc0, acc1;
-    uint32_t rd = lane16 + (uint32_t)(p.ck & 3) * kChunkBytes;
-    f32x4 a_nx = lds_read4(rd);   // A operands are fetched one quad ahead of the MFMAs that use them
+    constexpr int NQ = NP * 2 * QPU;
+    f32x16 accA0, accA1, accB0, accB1;   // pair P uses A* when P is even, B* when odd
+    uint32_t rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
+    f32x4 a_nx = lds_read4(rd);          // A operands are fetched one quad ahead of their MFMAs
 
-    static_for<0, NU>([&](auto uc) {
+    // LeakyReLU(v) = max(v, alpha*v) (0 < alpha < 1) on TWO accumulator registers at a time: one
+    // v_pk_mul_f32 + two v_max_f32 (gfx950 has no packed max).  Beside the fp32 MFMA every VALU
+    // instruction, packed or not, costs ~5-6 cycles of matrix-pipe time (tools/microbench/
+    // valu_cost.hip), so instruction count is what matters.  (asm: the builtin fmaxf adds a
+    // canonicalising v_max per element.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 alpha2 = {alpha, alpha};
+    auto store_act2 = [&](auto uc, auto rc, float v0, float v1) {
         constexpr int u = decltype(uc)::value;
-        f32x16& acc = (u & 1) ? acc1 : acc0;
-        f32x16& accp = (u & 1) ? acc0 : acc1;   // previous tile's accumulator
-        // accumulator starts as the bias of the 32 features of this tile (C-in of the first MFMA)
+        constexpr int r = decltype(rc)::value;   // even register index; handles r and r+1
+#ifdef NERF_DIAG_NOACT   // timing-only diagnostic: no activation math
+        const float y0 = v0, y1 = v1;
+#else
+        f32x2 v = {v0, v1}, av;
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(av) : "v"(v), "v"(alpha2));
+        float y0, y1;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y0) : "v"(v0), "v"(av[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(y1) : "v"(v1), "v"(av[1]));
+#endif
+        if constexpr (BODY == BODY_PE) { xin[u * 16 + r] = y0; xin[u * 16 + r + 1] = y1; }
+        else if constexpr (BODY == BODY_LAST) { xc[u * 16 + r] = y0; xc[u * 16 + r + 1] = y1; }
+        else if constexpr (u >= 2 * NP - 2) { xin[u * 16 + r] = y0; xin[u * 16 + r + 1] = y1; }   // last pair: in place
+        else { xnext[u * 16 + r] = y0; xnext[u * 16 + r + 1] = y1; }
+    };
+
+    static_for<0, NP>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        f32x16& acc0 = (P & 1) ? accB0 : accA0;
+        f32x16& acc1 = (P & 1) ? accB1 : accA1;
+        f32x16& prv0 = (P & 1) ? accA0 : accB0;   // previous pair's accumulators
+        f32x16& prv1 = (P & 1) ? accA1 : accB1;
+        // accumulators start as the bias of their 32 features (C-in of the first MFMA)
         static_for<0, 4>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const f32x4 b = lds_read4(cb_h + bias_off_bytes + (u * 32 + g * 8) * 4);
-            acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+            const f32x4 b0 = lds_read4(cb_h + bias_off_bytes + ((2 * P) * 32 + g * 8) * 4);
+            const f32x4 b1 = lds_read4(cb_h + bias_off_bytes + ((2 * P + 1) * 32 + g * 8) * 4);
+            acc0[4 * g + 0] = b0[0]; acc0[4 * g + 1] = b0[1]; acc0[4 * g + 2] = b0[2]; acc0[4 * g + 3] = b0[3];
+            acc1[4 * g + 0] = b1[0]; acc1[4 * g + 1] = b1[1]; acc1[4 * g + 2] = b1[2]; acc1[4 * g + 3] = b1[3];
         });
         static_for<0, QPU>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int Q = u * QPU + q;
-            // mid-chunk sync of the chunk quad Q lives in (p.ck still names that chunk here)
-            if constexpr (Q % kChunkQuads == 8) pipe_sync(p, wsrc_lane, wave);
-            const f32x4 a4 = a_nx;
-            if constexpr (Q + 1 < NQ) {
-                if constexpr ((Q + 1) % kChunkQuads == 0) {
-                    p.ck += 1;
-                    rd = lane16 + (uint32_t)(p.ck & 3) * kChunkBytes;
-                }
-                a_nx = lds_read4(rd + ((Q + 1) % kChunkQuads) * kQuadBytes);
-            }
-            static_for<0, 4>([&](auto ec) {
-                constexpr int e = decltype(ec)::value;
-                if constexpr (BODY == BODY_PE) {
-                    constexpr int s = 4 * q + e;
-                    if constexpr (s < 17) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xpe[s], acc, 0, 0, 0);
-                } else if constexpr (BODY == BODY_HID) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xin[4 * q + e], acc, 0, 0, 0);
-                } else if constexpr (BODY == BODY_SKIP) {
-                    if constexpr (q < kQpuPE) {
-                        constexpr int s = 4 * q + e;
-                        if constexpr (s < 17) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xpe[s], acc, 0, 0, 0);
-                    } else {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xin[4 * (q - kQpuPE) + e], acc, 0, 0, 0);
+            f32x4 a4[2];
+            static_for<0, 2>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int Q = (P * QPU + q) * 2 + t;
+                // mid-chunk sync of the chunk quad Q lives in (p.ck still names that chunk here)
+                // the chunk's last sync-point may fall in a short tail: then all 4 pieces go at once
+                constexpr int left = NQ - Q;   // quads left in this body including Q
+                if constexpr (Q % kChunkQuads == 8) pipe_sync(p, left <= 6);
+                // (tail of the body measured from the sync quad: left + distance > 6 <=> not all-at-once)
+                if constexpr (Q % kChunkQuads == 10 && left + 2 > 6) pipe_piece(p, 1);
+                if constexpr (Q % kChunkQuads == 12 && left + 4 > 6) pipe_piece(p, 2);
+                if constexpr (Q % kChunkQuads == 14 && left + 6 > 6) pipe_piece(p, 3);
+                a4[t] = a_nx;
+                if constexpr (Q + 1 < NQ) {
+                    if constexpr ((Q + 1) % kChunkQuads == 0) {
+                        p.ck += 1;
+                        rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
                     }
-                } else {
-                    if constexpr (q < kQpuHid) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xin[4 * q + e], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xdir[4 * (q - kQpuHid) + e], acc, 0, 0, 0);
+                    a_nx = lds_read4(rd + ((Q + 1) % kChunkQuads) * kQuadBytes);
                 }
             });
-            // deferred epilogue of the previous tile, placed in the shadow of this tile's MFMAs
-            if constexpr (q == 2 && u > 0) {
-                static_for<0, 16>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    const float v = accp[r];
-                    const float y = fmaxf(v, alpha * v);
-                    if constexpr (BODY == BODY_PE) xin[(u - 1) * 16 + r] = y;
-                    else if constexpr (BODY == BODY_LAST) xc[(u - 1) * 16 + r] = y;
-                    else xnext[(u - 1) * 16 + r] = y;
+            static_for<0, 4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                constexpr int s = 4 * q + e;
+                bool live = true;
+                float b = 0.f;
+                if constexpr (BODY == BODY_PE) {
+                    if constexpr (s < 17) b = xpe[s]; else live = false;
+                } else if constexpr (BODY == BODY_HID) {
+                    b = xin[s];
+                } else if constexpr (BODY == BODY_SKIP) {
+                    if constexpr (q < kQpuPE) { if constexpr (s < 17) b = xpe[s]; else live = false; }
+                    else b = xin[s - 4 * kQpuPE];
+                } else {
+                    if constexpr (q < kQpuHid) b = xin[s]; else b = xdir[s - 4 * kQpuHid];
+                }
+                if (live) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][e], b, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][e], b, acc1, 0, 0, 0);
+                }
+            });
+            // Deferred epilogue of the previous pair, spread over this pair's MFMA gaps: the VALU work
+            // hides only while each 64-cycle MFMA gap carries a few instructions, so it is dealt out
+            // kEpi elements per quad-pair (8 MFMAs) instead of in one block.
+            constexpr int kEpi = QPU >= 17 ? 1 : (16 + QPU - 2) / (QPU - 1);   // register PAIRS per q, q >= 1
+            if constexpr (P > 0 && q >= 1) {
+                static_for<0, kEpi>([&](auto ic) {
+                    constexpr int idx = (q - 1) * kEpi + decltype(ic)::value;   // 0..15 over the pair of tiles
+                    if constexpr (idx < 16) {
+                        constexpr int r = (idx & 7) * 2;
+                        if constexpr (idx < 8) store_act2(std::integral_constant<int, 2 * P - 2>{}, std::integral_constant<int, r>{}, prv0[r], prv0[r + 1]);
+                        else store_act2(std::integral_constant<int, 2 * P - 1>{}, std::integral_constant<int, r>{}, prv1[r], prv1[r + 1]);
+                    }
                 });
             }
-            // last chain of an in-place layer: tile t of xin is dead once its 4 quads are consumed
-            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && u == NU - 1) {
+            // last pair of an in-place layer: tile t of xin is dead once its 4 quads (4t..4t+3) are
+            // consumed; copy xnext back 4 registers per quad over the following 4 quads
+            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && P == NP - 1) {
                 constexpr int qh = BODY == BODY_SKIP ? q - kQpuPE : q;
-                if constexpr (qh >= 0 && (qh & 3) == 3 && (qh >> 2) < 7) {
-                    constexpr int t = qh >> 2;
-                    static_for<0, 16>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
+                if constexpr (qh >= 4 && qh < 28) {
+                    constexpr int t = (qh - 4) >> 2;
+                    constexpr int r0 = ((qh - 4) & 3) * 4;
+                    static_for<0, 4>([&](auto rc) {
+                        constexpr int r = r0 + decltype(rc)::value;
                         xin[t * 16 + r] = xnext[t * 16 + r];
                     });
                 }
             }
         });
     });
-    {   // epilogue of the last tile (its inputs are dead: write in place)
-        f32x16& accl = ((NU - 1) & 1) ? acc1 : acc0;
-        static_for<0, 16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const float v = accl[r];
-            const float y = fmaxf(v, alpha * v);
-            if constexpr (BODY == BODY_LAST) xc[(NU - 1) * 16 + r] = y;
-            else xin[(NU - 1) * 16 + r] = y;
+    {   // epilogue of the last pair
+        f32x16& l0 = ((NP - 1) & 1) ? accB0 : accA0;
+        f32x16& l1 = ((NP - 1) & 1) ? accB1 : accA1;
+        static_for<0, 8>([&](auto rc) {
+            constexpr int r = decltype(rc)::value * 2;
+            store_act2(std::integral_constant<int, 2 * NP - 2>{}, std::integral_constant<int, r>{}, l0[r], l0[r + 1]);
+            store_act2(std::integral_constant<int, 2 * NP - 1>{}, std::integral_constant<int, r>{}, l1[r], l1[r + 1]);
         });
     }
-    if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, wsrc_lane, wave);
+    if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, true);
     p.ck += 1;  // every body starts on a chunk boundary
 }
 
@@ -195,24 +284,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
     for (int i = tid; i < kConstFloats / 4; i += 256)
         reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
 
-    const char* wsrc_lane = reinterpret_cast<const char*>(a.wstream) + wave * (4 * kQuadBytes) + lane * 16;
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
+    p.wbase = reinterpret_cast<const char*>(a.wstream);
+    p.voff = wave * (4 * kQuadBytes) + lane * 16;
+    p.wave_lds = wave * (4 * kQuadBytes);
     __syncthreads();   // const region visible; no DMA in flight yet
-    // pipeline prologue: chunks 0,1,2 in flight, chunk 0 landed for everyone
+    // pipeline prologue: chunks 0 .. R-2 in flight, chunk 0 landed for everyone
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        dma_issue(wsrc_lane, p.src_next, c, wave);
+    for (int c = 0; c < kRingChunks - 1; ++c) {
+        p.cur_src = p.wbase + (size_t)p.src_next * kChunkBytes;
+        p.cur_dst = kLdsRing + c * kChunkBytes + p.wave_lds;
         p.src_next += 1;
+        dma_piece(p.cur_src, p.voff, p.cur_dst);
+        dma_piece(p.cur_src, p.voff + kQuadBytes, p.cur_dst + kQuadBytes);
+        dma_piece(p.cur_src, p.voff + 2 * kQuadBytes, p.cur_dst + 2 * kQuadBytes);
+        dma_piece(p.cur_src, p.voff + 3 * kQuadBytes, p.cur_dst + 3 * kQuadBytes);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingChunks - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    float xin[128], xnext[112], xpe[17], xdir[12], xc[64];
+    float xin[128], xnext[96], xpe[17], xdir[12], xc[64];
 
+    unsigned long long t0 = 0, t1 = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)t0; (void)t1; (void)acc_t;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        STAMP(t0);
         // ---------------- tile prologue: sample position + encodings ----------------
         const long long m = tile * 128 + wave * 32 + j;
         const bool valid = m < a.M;
@@ -248,15 +347,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
         }
 
         // ---------------- the 9 MFMA layers ----------------
-        layer_body<BODY_PE>(p, wsrc_lane, wave, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        STAMP(t1); acc_t[0] += t1 - t0;
+        layer_body<BODY_PE>(p, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
-            if (l == 4)
-                layer_body<BODY_SKIP>(p, wsrc_lane, wave, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
-            else
-                layer_body<BODY_HID>(p, wsrc_lane, wave, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+            if (l == 4) {
+                layer_body<BODY_SKIP>(p, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+                STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
+            } else {
+                layer_body<BODY_HID>(p, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+                STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
+            }
         }
-        layer_body<BODY_LAST>(p, wsrc_lane, wave, lane16, cb_h, kConstBias8 * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        layer_body<BODY_LAST>(p, lane16, cb_h, kConstBias8 * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        STAMP(t1); acc_t[4] += t1 - t0;
 
         // ---------------- heads on the VALU ----------------
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -301,7 +406,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
             out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = o3 + bh[3];
             *reinterpret_cast<f32x4*>(a.raw + m * 4) = out;
         }
+        STAMP(t0); acc_t[5] += t0 - t1; acc_t[6] += 1;
     }
+#ifdef NERF_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) g_stamps[i] = acc_t[i];
+#endif
     // drain the run-ahead weight prefetch before the wave (and its LDS allocation) goes away
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -312,6 +422,13 @@ void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream) {
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
     hipLaunchKernelGGL(mlp_fp32_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
+
+#ifdef NERF_STAMPS
+extern "C" void nerf_debug_read_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 void mlp_fp32_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fp32_kernel),
@@ -354,7 +471,8 @@ void pack_weights_fp32(const float* blob, float* stream_out, float* const_out) {
         float* base = stream_out + chunk * (kChunkBytes / 4);
         for (int u = 0; u < NU; ++u)
             for (int q = 0; q < QPU; ++q) {
-                float* quad = base + (size_t)(u * QPU + q) * (kQuadBytes / 4);
+                // tiles are consumed in pairs: quad order is (pair, q, tile-of-pair)
+                float* quad = base + (size_t)(((u >> 1) * QPU + q) * 2 + (u & 1)) * (kQuadBytes / 4);
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 4; ++e) {
                         const int i = lane & 31, h = lane >> 5;

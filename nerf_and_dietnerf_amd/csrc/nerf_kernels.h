@@ -20,8 +20,8 @@ constexpr int kDirDim = 6 * kLd;       // 24
 constexpr int kQuadBytes = 1024;
 constexpr int kChunkQuads = 16;
 constexpr int kChunkBytes = kQuadBytes * kChunkQuads;   // 16 KiB = one LDS ring slot
-constexpr int kRingChunks = 4;
-constexpr int kRingBytes = kChunkBytes * kRingChunks;   // 64 KiB
+constexpr int kRingChunks = 8;   // power of two
+constexpr int kRingBytes = kChunkBytes * kRingChunks;   // 128 KiB
 
 // quads per output tile for each layer body
 constexpr int kQpuPE = 5;                 // 17 k-steps (15 sin/cos pairs + raw xyz) padded to 20
@@ -48,7 +48,7 @@ constexpr int kConstBytes = kConstFloats * 4;
 // LDS carve of the MLP kernel
 constexpr int kLdsRing = 0;
 constexpr int kLdsConst = kRingBytes;
-constexpr int kLdsTotal = kRingBytes + kConstBytes;   // 76,928 B
+constexpr int kLdsTotal = kRingBytes + kConstBytes;   // 142,464 B of the 160 KiB
 
 struct MlpArgs {
     const float* wstream;   // packed A-operand stream of one network (kStreamBytes)
