@@ -37,7 +37,10 @@ def render_image_sharded(model, c2w, fov, h, w, group=None, rgb_only=True, **kw)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     total = h * w
     begin, count = ray_slab(total, rank, world)
-    outs = model.render_image(c2w, fov, h, w, ray_begin=begin, ray_count=max(count, 1), device_out=True,
+    # a rank whose slab is empty (more ranks than rays) still renders one ray so that every rank
+    # owns tensors of the right rank/dtype for the collective; its rows are sliced away below
+    rb, rc = (begin, count) if count > 0 else (total - 1, 1)
+    outs = model.render_image(c2w, fov, h, w, ray_begin=rb, ray_count=rc, device_out=True,
                               rgb_only=rgb_only, **kw)
     res = []
     for o in outs:

@@ -1,0 +1,90 @@
+"""Host logic and the C-ABI surface (no GPU compute): the library loads, exports every symbol
+include/nerf_mi355.h declares, and fails loudly where it must."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_symbols_exported():
+    import nerf_and_dietnerf_amd as N
+    lib = N._lib.load()
+    text = open(os.path.join(ROOT, "include", "nerf_mi355.h")).read()
+    declared = set(re.findall(r"\b(nerf_[a-z_]+)\s*\(", text))
+    declared -= {"nerf_config", "nerf_outputs", "nerf_ctx"}
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in N._lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.nerf_abi_version() == N._lib.NERF_ABI_VERSION
+
+
+def test_blob_size_and_config_errors():
+    import nerf_and_dietnerf_amd as N
+    lib = N._lib.load()
+    cfg = N._lib.NerfConfig(5, 4, 2, 256, 128, 0.05, 2.0, 6.0, 0, 0)
+    assert lib.nerf_blob_size(ctypes.byref(cfg)) == 514332 == N.blob_size()
+    bad = N._lib.NerfConfig(5, 4, 3, 256, 128, 0.05, 2.0, 6.0, 0, 0)
+    assert lib.nerf_blob_size(ctypes.byref(bad)) == 0
+    assert "should be 1 or 2" in N._lib.last_error()                 # message of src/UtilsCV.py:138
+    h = ctypes.c_void_p()
+    assert lib.nerf_ctx_create(ctypes.byref(bad), ctypes.byref(h)) != 0 and not h.value
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    import nerf_and_dietnerf_amd as N
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        N.Context()
+
+
+def test_split_to_batches_matches_reference_semantics(oracle):
+    import nerf_and_dietnerf_amd as N
+    # src/UtilsNeuralRadianceField.py:32-49: [B]*k (+[-1] remainder), or [total] when total < B
+    assert N.get_size_of_splits(4096, 2500) == [2500]
+    assert N.get_size_of_splits(4096, 65536) == [4096] * 16
+    assert N.get_size_of_splits(2048, 22500) == [2048] * 10 + [-1]
+    for b, t in [(4096, 2500), (4096, 65536), (2048, 22500), (7, 7), (3, 10)]:
+        assert N.get_size_of_splits(b, t) == oracle.get_size_of_splits(b, t)
+        x = np.arange(t * 2, dtype=np.float32).reshape(t, 2)
+        parts = N.split_to_batches(x, b)
+        assert sum(p.shape[0] for p in parts) == t
+        np.testing.assert_array_equal(np.concatenate(parts), x)
+        assert [p.shape[0] for p in parts] == [p.shape[0] for p in oracle.split_to_batches(x, b)]
+    with pytest.raises(AssertionError):
+        N.split_to_batches(np.zeros((4, 2), np.float32), 0)
+
+
+def test_weights_helpers(oracle):
+    import nerf_and_dietnerf_amd as N
+    assert N.layer_shapes() == oracle.layer_shapes()
+    b = N.glorot_blob(3)
+    np.testing.assert_array_equal(b, oracle.glorot_blob(3))
+    assert b.size == 514332 and b.dtype == np.float32
+    layers = oracle.unpack_blob(b)
+    assert all(np.all(bias == 0) for _, bias in layers)
+    with pytest.raises(Exception, match="should be 1 or 2"):
+        N.layer_shapes(n_angles=0)
+
+
+def test_ray_slab_partition():
+    import nerf_and_dietnerf_amd as N
+    for total, world in [(65536, 8), (65536, 1), (2500, 8), (22500, 4), (7, 8), (640000, 8)]:
+        slabs = [N.ray_slab(total, r, world) for r in range(world)]
+        assert slabs[0][0] == 0
+        assert sum(c for _, c in slabs) == total
+        for (b0, c0), (b1, _) in zip(slabs, slabs[1:]):
+            assert b1 == b0 + c0 or (c0 == 0 and b1 == total)
+        per = -(-total // world)
+        assert all(c <= per for _, c in slabs)
+    assert N.ray_slab(65536, 3, 8) == (3 * 8192, 8192)            # whole rows when H % P == 0
