@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -155,10 +155,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic (random-init Glorot weights, sphere pose, "
                                                           "on-device Philox draws)",
-            "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine, fp32 (BASELINE configs[1])",
+            "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine (BASELINE configs[1]); contractions in " + ("exact fp32 MFMA" if dtype == "f32" else "3-pass split-fp16 MFMA, fp32 accumulate"),
                        "rays_per_step": total, "mlp_rows_per_ray": SC + SC + SF,
                        "parallelism": f"ray-sharded x{world}, one all-gather of RGB per frame"},
-            "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel (fused PE + 11-layer MLP)",
+            "roofline": {"bound": "mfma", "kernel": ("mlp_fp32_kernel" if dtype == "f32" else "mlp_f16x3_kernel") + " (fused PE + 11-layer MLP)",
                          "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[dtype], "traffic": traffic,
                          "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),

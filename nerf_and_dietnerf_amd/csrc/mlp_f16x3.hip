@@ -1,0 +1,429 @@
+// mlp_f16x3.hip -- fused positional-encoding + 11-layer NeRF MLP forward on the fp16 matrix cores with
+// fp32-class accuracy: every fp32 operand is split x = hi + lo (two fp16 values, 22 significant bits)
+// and each product is formed in three MFMA passes  hi*hi + lo*hi + hi*lo  (the lo*lo term, 2^-22
+// relative, is dropped), accumulated in fp32 by v_mfma_f32_32x32x16_f16.
+//
+// Same reference chain as mlp_fp32.hip (src/UtilsCV.py:584-599,124-143; src/UtilsNRF.py:52-85;
+// src/NeRF.py:316-339) and the same kernel skeleton: one wave per SIMD, 32 samples per wave on the
+// lane, accumulator registers re-used as the next layer's B operand (here: converted to packed fp16
+// hi/lo fragments by the epilogue), weights streamed L2 -> LDS ring by LDS-DMA.  Differences:
+//   * k-step = 16 (one 32x32x16 MFMA): fragment element e of lane half h of k-step (t,s) is feature
+//     32t + 16s + 8(e>>2) + 4h + (e&3) -- the accumulator-as-operand order of the 32x32 C/D layout;
+//   * the weight stream holds an fp16 hi fragment and an fp16 lo fragment per (tile, k-step);
+//   * the sigma head (280 -> 1) rides the MFMA as a 5th output tile of layer 8 (its inputs only
+//     exist as fp16 hi/lo fragments); the rgb head (128 -> 3) stays on the VALU in fp32.
+// Measured accuracy (tests/test_gpu_parity.py): final RGB within 1e-4 of the fp32 oracle.
+#include "mlp_common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace nerf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- stream geometry (quads of 1 KiB = one fp16 A fragment: 64 lanes x 8 halfs) ----
+constexpr int kHStepsPE = 3;      // 33 inputs -> 48 slots
+constexpr int kHStepsHid = 16;
+constexpr int kHStepsDir = 2;     // 24 inputs -> 32 slots
+constexpr int kHQpuPE = 2 * kHStepsPE;                       // hi + lo fragment per k-step
+constexpr int kHQpuHid = 2 * kHStepsHid;
+constexpr int kHQpuSkip = kHQpuPE + kHQpuHid;
+constexpr int kHQpuLast = kHQpuHid + 2 * kHStepsDir;
+constexpr int kHTilesLast = 5;    // 4 x 32 features of layer 8 + the sigma row
+constexpr int kHChunksPE = (8 * kHQpuPE + 15) / 16;          // 3
+constexpr int kHChunksHid = (8 * kHQpuHid) / 16;             // 16
+constexpr int kHChunksSkip = (8 * kHQpuSkip + 15) / 16;      // 19
+constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + 15) / 16;   // 12
+constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 130
+// constant region (floats)
+constexpr int kHConstBias = 0;        // 8 x 256
+constexpr int kHConstBias8 = 2048;    // 128
+constexpr int kHConstBiasSig = 2176;  // 32: row 0 = sigma bias
+constexpr int kHConstWrgb = 2208;     // [3][128]
+constexpr int kHConstBHead = 2592;    // b_r, b_g, b_b, (unused)
+constexpr int kHConstFloats = 2608;
+
+static_assert(kHStreamChunks * (size_t)kChunkBytes == kStreamBytesF16, "stream size mismatch");
+static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
+
+template <int BODY>
+__device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
+                                             float alpha, h8 (&xh)[16], h8 (&xl)[16], h8 (&nh)[14],
+                                             h8 (&nl)[14], const h8 (&peh)[3], const h8 (&pel)[3],
+                                             const h8 (&dh)[2], const h8 (&dl)[2], float (&xc)[64],
+                                             float& sigma_raw) {
+    constexpr int NU = BODY == BODY_LAST ? kHTilesLast : 8;
+    constexpr int NSTEP = BODY == BODY_PE ? kHStepsPE : BODY == BODY_HID ? kHStepsHid
+                          : BODY == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
+    constexpr int QPU = 2 * NSTEP;
+    constexpr int NQ = NU * QPU;
+    f32x16 acc0, acc1;
+    uint32_t rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
+    f32x4 a_nx = lds_read4(rd);   // fragments are fetched one quad ahead of their MFMAs
+
+    // one accumulator register of a finished tile: LeakyReLU, then either keep fp32 (layer 8 -> heads)
+    // or split into fp16 hi/lo and drop into the fragment it feeds in the next layer
+    auto finish = [&](auto uc, auto rc, float v) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int r = decltype(rc)::value;
+        if constexpr (BODY == BODY_LAST && u == kHTilesLast - 1) {
+            if constexpr (r == 0) sigma_raw = v;              // raw sigma: no activation (src/NeRF.py:336)
+        } else {
+            const float av = alpha * v;
+            float y;
+            asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(v), "v"(av));
+            if constexpr (BODY == BODY_LAST) {
+                xc[u * 16 + r] = y;
+            } else {
+                const _Float16 hi = (_Float16)y;
+                const _Float16 lo = (_Float16)(y - (float)hi);
+                constexpr int n = 2 * u + (r >> 3), e = r & 7;
+                if constexpr (BODY == BODY_PE || u == NU - 1) { xh[n][e] = hi; xl[n][e] = lo; }   // in place
+                else { nh[n][e] = hi; nl[n][e] = lo; }
+            }
+        }
+    };
+
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        f32x16& acc = (u & 1) ? acc1 : acc0;
+        f32x16& prv = (u & 1) ? acc0 : acc1;
+        static_for<0, 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const f32x4 b = lds_read4(cb_h + bias_off_bytes + (u * 32 + g * 8) * 4);
+            acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+        });
+        static_for<0, NSTEP>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            f32x4 araw[2];
+            static_for<0, 2>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int Q = u * QPU + 2 * n + t;
+                constexpr int left = NQ - Q;
+                if constexpr (Q % kChunkQuads == 8) pipe_sync(p, left <= 6);
+                if constexpr (Q % kChunkQuads == 10 && left + 2 > 6) pipe_piece(p, 1);
+                if constexpr (Q % kChunkQuads == 12 && left + 4 > 6) pipe_piece(p, 2);
+                if constexpr (Q % kChunkQuads == 14 && left + 6 > 6) pipe_piece(p, 3);
+                araw[t] = a_nx;
+                if constexpr (Q + 1 < NQ) {
+                    if constexpr ((Q + 1) % kChunkQuads == 0) {
+                        p.ck += 1;
+                        rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
+                    }
+                    a_nx = lds_read4(rd + ((Q + 1) % kChunkQuads) * kQuadBytes);
+                }
+            });
+            const h8 a_hi = __builtin_bit_cast(h8, araw[0]);
+            const h8 a_lo = __builtin_bit_cast(h8, araw[1]);
+            h8 b_hi, b_lo;
+            if constexpr (BODY == BODY_PE) { b_hi = peh[n]; b_lo = pel[n]; }
+            else if constexpr (BODY == BODY_HID) { b_hi = xh[n]; b_lo = xl[n]; }
+            else if constexpr (BODY == BODY_SKIP) {
+                if constexpr (n < kHStepsPE) { b_hi = peh[n]; b_lo = pel[n]; }
+                else { b_hi = xh[n - kHStepsPE]; b_lo = xl[n - kHStepsPE]; }
+            } else {
+                if constexpr (n < kHStepsHid) { b_hi = xh[n]; b_lo = xl[n]; }
+                else { b_hi = dh[n - kHStepsHid]; b_lo = dl[n - kHStepsHid]; }
+            }
+            // x*w ~= hi*hi + lo_w*hi_x + hi_w*lo_x  (small terms first)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
+            // deferred epilogue of the previous tile, dealt out over this tile's k-steps
+            // (2 registers per k-step: done by step 7, before the copy-back below needs fragments 12/13)
+            constexpr int kEpi = NSTEP >= 8 ? 2 : (16 + NSTEP - 1) / NSTEP;
+            if constexpr (u > 0) {
+                static_for<0, kEpi>([&](auto ic) {
+                    constexpr int r = n * kEpi + decltype(ic)::value;
+                    if constexpr (r < 16) finish(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, prv[r]);
+                });
+            }
+            // last tile of an in-place layer: fragments of x-in die as their k-step is consumed
+            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && u == NU - 1) {
+                constexpr int m = BODY == BODY_SKIP ? n - kHStepsPE : n;
+                if constexpr (m >= 1 && m - 1 < 14) { xh[m - 1] = nh[m - 1]; xl[m - 1] = nl[m - 1]; }
+            }
+        });
+    });
+    {
+        f32x16& last = ((NU - 1) & 1) ? acc1 : acc0;
+        static_for<0, 16>([&](auto rc) {
+            finish(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
+        });
+    }
+    if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, true);
+    p.ck += 1;
+}
+
+// fp32 values -> fp16 hi / lo fragments
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(v[e] - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const uint32_t lane16 = kLdsRing + lane * 16;
+    const uint32_t cb_h = kLdsConst + h * 16;
+
+    const long long ntiles = (a.M + 127) / 128;
+    if ((long long)blockIdx.x >= ntiles) return;
+
+    for (int i = tid; i < kHConstFloats / 4; i += 256)
+        reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
+
+    Pipe p;
+    p.ck = 0;
+    p.src_next = 0;
+    p.n_chunks = kHStreamChunks;
+    p.wbase = reinterpret_cast<const char*>(a.wstream);
+    p.voff = wave * (4 * kQuadBytes) + lane * 16;
+    p.wave_lds = wave * (4 * kQuadBytes);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kRingChunks - 1; ++c) {
+        p.cur_src = p.wbase + (size_t)p.src_next * kChunkBytes;
+        p.cur_dst = kLdsRing + c * kChunkBytes + p.wave_lds;
+        p.src_next += 1;
+        dma_piece(p.cur_src, p.voff, p.cur_dst);
+        dma_piece(p.cur_src, p.voff + kQuadBytes, p.cur_dst + kQuadBytes);
+        dma_piece(p.cur_src, p.voff + 2 * kQuadBytes, p.cur_dst + 2 * kQuadBytes);
+        dma_piece(p.cur_src, p.voff + 3 * kQuadBytes, p.cur_dst + 3 * kQuadBytes);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingChunks - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    h8 xh[16], xl[16], nh[14], nl[14], peh[3], pel[3], dh[2], dl[2];
+    float xc[64];
+    float sigma_raw = 0.f;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m = tile * 128 + wave * 32 + j;
+        const bool valid = m < a.M;
+        const long long mm = valid ? m : a.M - 1;
+        float px, py, pz, dx, dy, dz;
+        if (a.mode == 0) {
+            const long long ray = mm / a.S;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(a.in_a + ray * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(a.in_b + ray * 4);
+            const float zz = a.z[mm];
+            px = __fadd_rn(o[0], __fmul_rn(d[0], zz));
+            py = __fadd_rn(o[1], __fmul_rn(d[1], zz));
+            pz = __fadd_rn(o[2], __fmul_rn(d[2], zz));
+            dx = d[0]; dy = d[1]; dz = d[2];
+        } else {
+            px = a.in_a[mm * 3 + 0]; py = a.in_a[mm * 3 + 1]; pz = a.in_a[mm * 3 + 2];
+            dx = a.in_b[mm * 3 + 0]; dy = a.in_b[mm * 3 + 1]; dz = a.in_b[mm * 3 + 2];
+        }
+        const float kPi = 3.1415927410125732f;
+        // 24 slots per lane half: h=0: sin of the 15 angles, x, y, z; h=1: cos of the 15 angles
+        float pv[24];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = c == 0 ? px : c == 1 ? py : pz;
+#pragma unroll
+            for (int k = 0; k < kLx; ++k) pv[c * kLx + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+        }
+        pv[15] = h ? 0.f : px; pv[16] = h ? 0.f : py; pv[17] = h ? 0.f : pz;
+#pragma unroll
+        for (int i = 18; i < 24; ++i) pv[i] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] = pv[n * 8 + e];
+            split8(t8, peh[n], pel[n]);
+        }
+        float dv[16];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = c == 0 ? dx : c == 1 ? dy : dz;
+#pragma unroll
+            for (int k = 0; k < kLd; ++k) dv[c * kLd + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+        }
+#pragma unroll
+        for (int i = 12; i < 16; ++i) dv[i] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] = dv[n * 8 + e];
+            split8(t8, dh[n], dl[n]);
+        }
+
+        layer_body_h<BODY_PE>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            if (l == 4)
+                layer_body_h<BODY_SKIP>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            else
+                layer_body_h<BODY_HID>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        }
+        layer_body_h<BODY_LAST>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+
+        // rgb head (128 -> 3) on the VALU in fp32
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w0 = lds_read4(cb_h + (kHConstWrgb + 0 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w1 = lds_read4(cb_h + (kHConstWrgb + 1 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w2 = lds_read4(cb_h + (kHConstWrgb + 2 * 128 + t * 32 + g * 8) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = xc[t * 16 + g * 4 + e];
+                    o0 = fmaf(w0[e], x, o0);
+                    o1 = fmaf(w1[e], x, o1);
+                    o2 = fmaf(w2[e], x, o2);
+                }
+            }
+        }
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        const f32x4 bh = lds_read4(kLdsConst + kHConstBHead * 4);
+        if (valid && h == 0) {
+            f32x4 out;
+            out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = sigma_raw;
+            *reinterpret_cast<f32x4*>(a.raw + m * 4) = out;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream) {
+    if (a.M <= 0) return;
+    const long long ntiles = (a.M + 127) / 128;
+    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    hipLaunchKernelGGL(mlp_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+}
+
+void mlp_f16x3_set_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side packing: blob (Keras get_weights() order) -> fp16 hi/lo fragment stream + fp32 constants
+// ------------------------------------------------------------------------------------------------
+namespace {
+// fp32 -> fp16 round-to-nearest-even and back, by bit manipulation (no host _Float16 runtime needed)
+uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x200u : 0));   // inf / nan
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                     // overflow -> inf
+    if (x < 0x33000001u) return (uint16_t)sign;                                                  // < 2^-25 -> 0
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }          // subnormal half
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7FFFFFu; }
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1))) q += 1;   // may carry into the exponent: correct
+    return (uint16_t)(sign | (base + q));
+}
+float f16_to_f32(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+    const uint32_t e = (hbits >> 10) & 0x1F, m = hbits & 0x3FF;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { float f = (float)m * 5.9604644775390625e-08f; memcpy(&x, &f, 4); x |= sign; }   // m * 2^-24
+    } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+int h_pe_row(int v, int h) {   // slot v (0..23) of lane half h -> row of the (33, .) kernel; -1 = pad
+    if (v < 15) { const int c = v / 5, k = v % 5; return c * 11 + 1 + 2 * k + h; }
+    if (v < 18 && h == 0) return (v - 15) * 11;
+    return -1;
+}
+int h_hid_row(int n, int e, int h) { const int t = n >> 1, s = n & 1; return 32 * t + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); }
+int h_dir_row(int v, int h) {   // slot v (0..15) -> row of the 24 dir features
+    if (v < 12) { const int c = v / 4, k = v % 4; return c * 8 + 2 * k + h; }
+    return -1;
+}
+struct HLayer { const float* k; const float* b; int in, out; };
+}  // namespace
+
+void pack_weights_f16x3(const float* blob, void* stream_out, float* const_out) {
+    static const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                      {256, 256}, {256, 256}, {280, 128}, {128, 3}, {280, 1}};
+    HLayer L[11];
+    size_t off = 0;
+    for (int i = 0; i < 11; ++i) {
+        L[i].in = shapes[i][0]; L[i].out = shapes[i][1];
+        L[i].k = blob + off; off += (size_t)L[i].in * L[i].out;
+        L[i].b = blob + off; off += L[i].out;
+    }
+    memset(stream_out, 0, kStreamBytesF16);
+    memset(const_out, 0, kConstBytes);
+    uint16_t* base = reinterpret_cast<uint16_t*>(stream_out);
+    size_t chunk = 0;
+    auto emit_body = [&](int layer, int body) {
+        const int NU = body == BODY_LAST ? kHTilesLast : 8;
+        const int NSTEP = body == BODY_PE ? kHStepsPE : body == BODY_HID ? kHStepsHid
+                          : body == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
+        uint16_t* b0 = base + chunk * (kChunkBytes / 2);
+        for (int u = 0; u < NU; ++u)
+            for (int n = 0; n < NSTEP; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = lane & 31, h = lane >> 5;
+                        int row;
+                        if (body == BODY_PE) row = h_pe_row(n * 8 + e, h);
+                        else if (body == BODY_HID) row = h_hid_row(n, e, h);
+                        else if (body == BODY_SKIP) {
+                            if (n < kHStepsPE) row = h_pe_row(n * 8 + e, h);
+                            else row = kXyzDim + h_hid_row(n - kHStepsPE, e, h);
+                        } else {
+                            if (n < kHStepsHid) row = h_hid_row(n, e, h);
+                            else { const int r = h_dir_row((n - kHStepsHid) * 8 + e, h); row = r < 0 ? -1 : kHidden + r; }
+                        }
+                        float w = 0.f;
+                        if (row >= 0) {
+                            if (body == BODY_LAST && u == kHTilesLast - 1) w = i == 0 ? L[10].k[row] : 0.f;   // sigma row
+                            else w = L[layer].k[(size_t)row * L[layer].out + 32 * u + i];
+                        }
+                        const uint16_t hi = f32_to_f16(w);
+                        const uint16_t lo = f32_to_f16(w - f16_to_f32(hi));
+                        const size_t q = (size_t)(u * NSTEP + n) * 2;
+                        b0[(q + 0) * (kQuadBytes / 2) + lane * 8 + e] = hi;
+                        b0[(q + 1) * (kQuadBytes / 2) + lane * 8 + e] = lo;
+                    }
+        chunk += (NU * NSTEP * 2 + kChunkQuads - 1) / kChunkQuads;
+    };
+    emit_body(0, BODY_PE);
+    for (int l = 1; l <= 3; ++l) emit_body(l, BODY_HID);
+    emit_body(4, BODY_SKIP);
+    for (int l = 5; l <= 7; ++l) emit_body(l, BODY_HID);
+    emit_body(8, BODY_LAST);
+    for (int l = 0; l < 8; ++l)
+        for (int f = 0; f < 256; ++f) const_out[kHConstBias + l * 256 + f] = L[l].b[f];
+    for (int f = 0; f < 128; ++f) const_out[kHConstBias8 + f] = L[8].b[f];
+    const_out[kHConstBiasSig + 0] = L[10].b[0];
+    for (int c = 0; c < 3; ++c)
+        for (int f = 0; f < 128; ++f) const_out[kHConstWrgb + c * 128 + f] = L[9].k[f * 3 + c];
+    for (int c = 0; c < 3; ++c) const_out[kHConstBHead + c] = L[9].b[c];
+}
+
+}  // namespace nerf

@@ -18,99 +18,15 @@
 //     (global_load_lds_dwordx4), one counted vmcnt + one s_barrier per 64 MFMAs, shared by the 4
 //     waves; A operands are read back with one ds_read_b128 per 4 MFMAs.
 //   * heads (128->3, 280->1) on the VALU; positional encoding in-register with a Cody-Waite sincos.
-#include "nerf_kernels.h"
-#include "nerf_device.h"
+#include "mlp_common.h"
 
 #include <math.h>
 #include <string.h>
 
-#include <type_traits>
-
 namespace nerf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LDS_AS __attribute__((address_space(3)))
-#define GLB_AS __attribute__((address_space(1)))
-
-__device__ __forceinline__ f32x4 lds_read4(uint32_t byte_off) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    return *reinterpret_cast<const f32x4*>(smem + byte_off);
-}
-
-struct Pipe {
-    int ck;             // chunk being consumed (monotonic; ring position = ck % kRingChunks)
-    int src_next;       // next chunk index of the cyclic weight stream to DMA (0..kStreamChunks-1)
-    const char* wbase;  // packed weight stream (wave-uniform)
-    uint32_t voff;      // this lane's byte offset inside a chunk: wave*4 KiB + lane*16
-    uint32_t wave_lds;  // wave*4 KiB
-    // the chunk whose 4 pieces are being dealt out after the latest sync
-    const char* cur_src;
-    uint32_t cur_dst;
-};
-
-// One LDS-DMA piece: global_load_lds_dwordx4 moves 1 KiB (64 lanes x 16 B) from
-// sbase + voff (per-lane byte offset) to LDS at m0_dst + lane*16.  A wave's share of a 16 KiB chunk
-// is 4 pieces.  Inline asm on purpose: with the builtin form hipcc (ROCm 7.2) treats every later
-// ds_read as possibly aliasing the in-flight DMA and degrades all its LDS waits to lgkmcnt(0); hidden
-// from the compiler, its ds_read waits stay counted and the DMA is ordered by our own vmcnt/barrier.
-// Each piece costs ~60 issue cycles, about one 64-cycle MFMA: pieces are dealt out one per MFMA gap
-// (4 in a row after the barrier cost ~170 idle MFMA cycles per chunk, measured).
-__device__ __forceinline__ void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-
-// Mid-chunk synchronisation point of chunk p.ck:
-//   vmcnt(4*(R-3)): this wave's share of chunk ck+1 has landed (only the 4 DMAs each of chunks
-//                ck+2 .. ck+R-2 may still be pending; R = kRingChunks);
-//   lgkmcnt(8): every ds_read of chunk ck-1 has returned (at most this chunk's first 8 pending);
-//   barrier:  => all waves' shares of ck+1 are visible, and ring slot (ck-1)%R is free for reuse.
-// Then issue chunk ck+R-1 into that free slot.
-__device__ __forceinline__ void pipe_piece(Pipe& p, int j) {
-#if !(defined(NERF_DIAG) && NERF_DIAG == 2)
-    dma_piece(p.cur_src, p.voff + j * kQuadBytes, p.cur_dst + j * kQuadBytes);
-#endif
-}
-
-__device__ __forceinline__ void pipe_sync(Pipe& p, bool all_pieces) {
-#if defined(NERF_DIAG) && NERF_DIAG == 2   // timing-only diagnostic: no wait, no barrier, no DMA
-    asm volatile("" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(4 * (kRingChunks - 3)) : "memory");
-#if !(defined(NERF_DIAG) && NERF_DIAG == 1)   // NERF_DIAG 1: timing-only, no barrier
-    __builtin_amdgcn_s_barrier();
-#endif
-    asm volatile("" ::: "memory");
-#endif
-    p.cur_src = p.wbase + (size_t)p.src_next * kChunkBytes;
-    p.cur_dst = kLdsRing + ((p.ck + kRingChunks - 1) & (kRingChunks - 1)) * kChunkBytes + p.wave_lds;
-    p.src_next = (p.src_next + 1 == kStreamChunks) ? 0 : p.src_next + 1;
-    pipe_piece(p, 0);
-    if (all_pieces) { pipe_piece(p, 1); pipe_piece(p, 2); pipe_piece(p, 3); }
-}
-
-enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
-
-#ifdef NERF_STAMPS   // diagnostic build only: per-phase cycle sums of wave 0 of workgroup 0
+#ifdef NERF_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define STAMP(var)                                                      \
-    do {                                                                \
-        __builtin_amdgcn_sched_barrier(0);                              \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                              \
-    } while (0)
-#else
-#define STAMP(var) do { } while (0)
 #endif
 
 // One dense layer, u-outer: for each 32-wide output tile run the whole K chain into one accumulator.
@@ -118,15 +34,6 @@ __device__ unsigned long long g_stamps[16];
 //   BODY_HID  : B = xin                      -> xin   (layers 1-3, 5-7; via xnext + staged copy-back)
 //   BODY_SKIP : B = [xpe, xin]               -> xin   (layer 4)
 //   BODY_LAST : B = [xin, xdir], 4 tiles     -> xc    (layer 8)
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 template <int BODY>
 __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
                                            uint32_t cb_h, int bias_off_bytes, float alpha,
@@ -287,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
+    p.n_chunks = kStreamChunks;
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (4 * kQuadBytes);

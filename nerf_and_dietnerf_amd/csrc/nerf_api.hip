@@ -45,8 +45,10 @@ struct DevBuf {
 };
 
 struct NetWeights {
-    float* stream = nullptr;   // kStreamBytes
-    float* cst = nullptr;      // kConstBytes
+    float* stream = nullptr;     // kStreamBytes      (fp32 MFMA operand stream)
+    float* cst = nullptr;        // kConstBytes
+    void* stream_h = nullptr;    // kStreamBytesF16   (fp16 hi/lo fragment stream)
+    float* cst_h = nullptr;      // kConstBytes
     bool loaded = false;
 };
 
@@ -106,8 +108,8 @@ int check_cfg(const nerf_config* cfg) {
         cfg->last_hidden_dim != kLast)
         return fail("fused kernel is specialised for Lx=%d Ld=%d hidden=%d last=%d (got %d %d %d %d)", kLx, kLd,
                     kHidden, kLast, cfg->n_pos_enc_xyz, cfg->n_pos_enc_dir, cfg->hidden_dim, cfg->last_hidden_dim);
-    if (cfg->precision != NERF_PRECISION_FP32)
-        return fail("precision %d is not available in this build (only NERF_PRECISION_FP32)", cfg->precision);
+    if (cfg->precision != NERF_PRECISION_FP32 && cfg->precision != NERF_PRECISION_F16X3)
+        return fail("unknown precision %d (NERF_PRECISION_FP32 = 0, NERF_PRECISION_F16X3 = 1)", cfg->precision);
     return 0;
 }
 
@@ -115,8 +117,10 @@ int check_cfg(const nerf_config* cfg) {
 int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const float* z, float* raw, long long M,
             int S, int mode) {
     if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
+    const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3;
     MlpArgs a;
-    a.wstream = c->net[which].stream; a.wconst = c->net[which].cst;
+    a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
+    a.wconst = f16 ? c->net[which].cst_h : c->net[which].cst;
     a.in_a = in_a; a.in_b = in_b; a.z = z; a.raw = raw; a.M = M; a.S = S; a.mode = mode;
     a.alpha = c->cfg.leaky_relu_alpha;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -132,7 +136,8 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         c->timed_rows += M;
         HIP_OK(hipEventRecord(e0, c->stream));
     }
-    launch_mlp_fp32(a, c->num_cus, c->stream);
+    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream);
+    else launch_mlp_fp32(a, c->num_cus, c->stream);
     if (c->timing) HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipGetLastError());
     return 0;
@@ -248,6 +253,7 @@ int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out) {
     }
     c->stream = c->own_stream;
     mlp_fp32_set_attributes();
+    mlp_f16x3_set_attributes();
     *out = c;
     return 0;
 }
@@ -260,7 +266,12 @@ void nerf_ctx_destroy(nerf_ctx* c) {
                       &c->b_in0, &c->b_in1, &c->b_in2, &c->b_in3};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : c->b_out) if (b.p) (void)hipFree(b.p);
-    for (auto& n : c->net) { if (n.stream) (void)hipFree(n.stream); if (n.cst) (void)hipFree(n.cst); }
+    for (auto& n : c->net) {
+        if (n.stream) (void)hipFree(n.stream);
+        if (n.cst) (void)hipFree(n.cst);
+        if (n.stream_h) (void)hipFree(n.stream_h);
+        if (n.cst_h) (void)hipFree(n.cst_h);
+    }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -287,7 +298,9 @@ int nerf_ctx_set_bounds(nerf_ctx* c, float near_b, float far_b) {
 
 int nerf_ctx_set_precision(nerf_ctx* c, int precision) {
     if (!c) return fail("ctx is NULL");
-    if (precision != NERF_PRECISION_FP32) return fail("precision %d is not available in this build", precision);
+    if (precision != NERF_PRECISION_FP32 && precision != NERF_PRECISION_F16X3)
+        return fail("unknown precision %d", precision);
+    HIP_OK(hipStreamSynchronize(c->stream));
     c->cfg.precision = precision;
     return 0;
 }
@@ -306,6 +319,14 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* blob, size_t n_floats
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(n.stream, st.data(), kStreamBytes, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(n.cst, cs.data(), kConstBytes, hipMemcpyHostToDevice));
+    // both operand formats are kept resident (2 x 2.1 MB per network) so precision can be switched per call
+    std::vector<uint16_t> sth(kStreamBytesF16 / 2);
+    std::vector<float> csh(kConstFloats);
+    pack_weights_f16x3(blob, sth.data(), csh.data());
+    if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16));
+    if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
+    HIP_OK(hipMemcpy(n.stream_h, sth.data(), kStreamBytesF16, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(n.cst_h, csh.data(), kConstBytes, hipMemcpyHostToDevice));
     n.loaded = true;
     return 0;
 }

@@ -34,6 +34,7 @@ constexpr int kChunksSkip = (8 * kQpuSkip + 15) / 16;  // 19
 constexpr int kChunksLast = (4 * kQpuLast + 15) / 16;  // 9
 constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksLast;  // 127
 constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
+constexpr size_t kStreamBytesF16 = size_t(130) * kChunkBytes;   // f16x3 stream (mlp_f16x3.hip)
 
 // ---- constant region (biases + head weights), floats ----
 constexpr int kConstBias = 0;                       // 8 x 256 hidden-layer biases (layers 0..7)
@@ -68,6 +69,11 @@ void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream);
 void mlp_fp32_set_attributes();
 // host-side packing of one network's blob (11 x (kernel(in,out), bias)) into stream + const
 void pack_weights_fp32(const float* blob, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
+
+// mlp_f16x3.hip
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream);
+void mlp_f16x3_set_attributes();
+void pack_weights_f16x3(const float* blob, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 
 // aux_kernels.hip
 void launch_raygen(const float* unused, const float c2w_host[16], float fov, int H, int W,

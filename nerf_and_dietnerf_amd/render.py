@@ -135,6 +135,11 @@ class Context:
         _lib.check(self.lib.nerf_ctx_set_bounds(self.h, near, far))
         self.cfg.near_boundary, self.cfg.far_boundary = near, far
 
+    def set_precision(self, precision: str) -> None:
+        """"fp32" (exact fp32 MFMA) or "f16x3" (3-pass split-fp16 MFMA, fp32 accumulate)."""
+        _lib.check(self.lib.nerf_ctx_set_precision(self.h, _PRECISIONS[precision]))
+        self.cfg.precision = _PRECISIONS[precision]
+
     def synchronize(self) -> None:
         _lib.check(self.lib.nerf_ctx_synchronize(self.h))
 

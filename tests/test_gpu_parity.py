@@ -257,3 +257,60 @@ def test_error_behaviour(nerf):
         nerf.ctx.load_weights(0, np.zeros(17, np.float32))   # wrong blob size
     with pytest.raises(RuntimeError):
         N.Context(hidden_dim=128)                            # unsupported geometry fails loudly
+
+
+# ---------------------------------------------------------------- f16x3 precision mode
+@pytest.fixture(scope="module")
+def nerf16(golden_ckpt):
+    """Same model, contractions on the fp16 matrix cores with 3-pass hi/lo splitting."""
+    import nerf_and_dietnerf_amd as N
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
+               "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
+    ren_cfg = {"n_render_samples_coarse": 64, "n_render_samples_fine": 128}
+    m = N.NeRF(net_cfg, ren_cfg, float(golden_ckpt["near"]), float(golden_ckpt["far"]), precision="f16x3")
+    m.set_weights(golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
+    return m
+
+
+def test_f16x3_model_predict(nerf16, nets, oracle, golden_vec):
+    import nerf_and_dietnerf_amd as N
+    o, d, z = golden_vec["rays_orig"], golden_vec["rays_dirs"], golden_vec["z_coarse"]
+    pts = oracle.sample_along_rays(o, d, z)[..., :3].reshape(-1, 3)
+    view = oracle.get_view_directions(z.shape[1], d, 2)
+    got = N.model_predict(nerf16.model_coarse, 4, 5, pts, view)
+    ref = golden_vec["raw_coarse"]
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    print("f16x3 raw rel err", err)
+    assert err <= 5e-5          # 22-bit operands, fp32 accumulate (fp32 path: 2e-5)
+    for m in (1, 31, 129, 1000):
+        got = N.model_predict(nerf16.model_fine, 4, 5, pts[:m], view[:m])
+        ref = oracle.model_predict(nets[1], pts[:m], view[:m])
+        assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_f16x3_render_parity(nerf16, golden_vec):
+    """The north-star bar holds in the fast mode too: <= 1e-4 max-abs RGB vs the fp32 oracle."""
+    o, d = golden_vec["rays_orig"], golden_vec["rays_dirs"]
+    rgb, w, T, a, c, z = nerf16.render(o, d, u_coarse=golden_vec["u_coarse"], u_fine=golden_vec["u_fine"])
+    err = np.abs(rgb - golden_vec["rgb"]).max()
+    print("f16x3 render rgb max-abs err", err)
+    assert err <= RGB_TOL
+    assert np.mean(np.abs(z - golden_vec["z"]) > 1e-5) < 2e-3
+    out = nerf16.render_image(golden_vec["c2w"], float(golden_vec["fov"]), 12, 12, seed=int(golden_vec["img12_seed"]))
+    assert np.abs(out[0] - golden_vec["img12_rgb"]).max() <= RGB_TOL
+
+
+def test_f16x3_psnr_and_large_inputs(nerf16, golden_ckpt, oracle, nets):
+    img = golden_ckpt["img_test"].astype(np.float32) / np.float32(255)
+    out = nerf16.render_image(golden_ckpt["c2w_test"], float(golden_ckpt["fov"]), 50, 50, seed=1)
+    assert abs(oracle.psnr(out[0], img) - float(golden_ckpt["recorded_psnr_test"])) <= 0.3
+    # coordinates far outside the trained volume (large activations): stays finite and close
+    import nerf_and_dietnerf_amd as N
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-8, 8, (512, 3)).astype(np.float32)
+    view = rng.uniform(-1, 1, (512, 3)).astype(np.float32)
+    got = N.model_predict(nerf16.model_fine, 4, 5, pts, view)
+    ref = oracle.model_predict(nets[1], pts, view)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
