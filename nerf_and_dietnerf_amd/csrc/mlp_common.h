@@ -15,6 +15,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
 
+__device__ __forceinline__ const char* smem_base() {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    return smem;
+}
+
 __device__ __forceinline__ f32x4 lds_read4(uint32_t byte_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     return *reinterpret_cast<const f32x4*>(smem + byte_off);
@@ -84,7 +89,6 @@ __device__ __forceinline__ void pipe_sync(Pipe& p, bool all_pieces) {
 enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
 
 #ifdef NERF_STAMPS   // diagnostic build only: per-phase cycle sums of wave 0 of workgroup 0
-extern __device__ unsigned long long g_stamps[16];
 #define STAMP(var)                                                      \
     do {                                                                \
         __builtin_amdgcn_sched_barrier(0);                              \

@@ -21,6 +21,27 @@
 namespace nerf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef uint32_t frag4 __attribute__((ext_vector_type(4)));   // one fp16 fragment = 4 dwords of 2 halfs
+
+// asm LDS read of one fragment into an AGPR quad, and the counted wait that retires it (see layer_body_h)
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag_asm(f32x4& dst, uint32_t base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(base), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_frag_asm(f32x4& reg) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(reg) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // RNE; v_cvt_pk_f16_f32
+    const h2 t = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+#ifdef NERF_STAMPS
+__device__ unsigned long long g_stamps_h[16];
+#endif
 
 // ---- stream geometry (quads of 1 KiB = one fp16 A fragment: 64 lanes x 8 halfs) ----
 constexpr int kHStepsPE = 3;      // 33 inputs -> 48 slots
@@ -47,53 +68,89 @@ constexpr int kHConstFloats = 2608;
 static_assert(kHStreamChunks * (size_t)kChunkBytes == kStreamBytesF16, "stream size mismatch");
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
 
-template <int BODY>
+// fp32 -> (hi, lo) with hi = the top 11 significand bits (exact in fp16) and lo = y - hi (exact in
+// fp32, then rounded to fp16): |lo| <= 2^-10 |y|, total representation error <= 2^-21 |y|.  Costs two
+// plain VALU ops (v_and, v_sub) instead of a v_cvt round trip: beside the fp16 MFMA, conversions and
+// moves are "8-cycle" instructions, plain arithmetic is nearly free (tools/microbench/valu_cost_f16.hip).
+__device__ __forceinline__ void split_trunc(float y, float& hi_f, float& lo_f) {
+    hi_f = __uint_as_float(__float_as_uint(y) & 0xFFFFE000u);
+    lo_f = y - hi_f;
+}
+
+// One dense layer on the fp16 matrix cores, u-outer (one accumulator chain per 32-wide output tile).
+// The epilogue of a tile (bias, LeakyReLU, hi/lo split, fp16 pack) is dealt out ONE accumulator
+// register per k-step over the NEXT tile's chain -- also across layer boundaries (PENDING: the
+// previous layer's last tile is finished during this layer's first tile), so no epilogue is exposed.
+//   fragments of the layer input live in xh/xl[16]; outputs of tiles 0..6 go to nh/nl and are copied
+//   back as the last tile's chain retires the k-steps that read them; tile 7 lands in xh/xl[14..15].
+template <int BODY, bool PENDING>
 __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
-                                             float alpha, h8 (&xh)[16], h8 (&xl)[16], h8 (&nh)[14],
-                                             h8 (&nl)[14], const h8 (&peh)[3], const h8 (&pel)[3],
-                                             const h8 (&dh)[2], const h8 (&dl)[2], float (&xc)[64],
-                                             float& sigma_raw) {
+                                             float alpha, f32x16 (&accs)[4],
+                                             frag4 (&xh)[16], frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14],
+                                             const frag4 (&peh)[3], const frag4 (&pel)[3], const frag4 (&dh)[2],
+                                             const frag4 (&dl)[2], float (&xc)[64], float& sigma_raw) {
     constexpr int NU = BODY == BODY_LAST ? kHTilesLast : 8;
     constexpr int NSTEP = BODY == BODY_PE ? kHStepsPE : BODY == BODY_HID ? kHStepsHid
                           : BODY == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
     constexpr int QPU = 2 * NSTEP;
     constexpr int NQ = NU * QPU;
-    f32x16 acc0, acc1;
-    uint32_t rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
-    f32x4 a_nx = lds_read4(rd);   // fragments are fetched one quad ahead of their MFMAs
+    // A fragments are fetched kPf quads (2 k-steps = 6 MFMAs = 192 cycles) ahead of their MFMAs.  The
+    // ds_read is inline asm with a hand-counted s_waitcnt: left to itself hipcc sinks the reads next to
+    // their MFMA (register pressure) and every k-step then waits out the LDS latency.  Destinations are
+    // AGPRs ("a"): plentiful here, legal as MFMA A operands, and never shuffled by the allocator between
+    // the read and its wait.  LDS returns in order, so lgkmcnt(kPf-1) before quad Q's use means "Q has
+    // landed" however many younger compiler-issued LDS reads are in flight (they only make it stricter).
+    constexpr int kPf = 4;
+    f32x4 pf[kPf];
+    const int ck0 = p.ck;   // chunk of quad 0 of this body; quad Q lives in chunk ck0 + Q/16
+    uint32_t rdbase[2];     // LDS address of the ring slot of an even / odd chunk (refreshed as chunks retire)
+    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kRingChunks - 1)) * kChunkBytes;
+    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kRingChunks - 1)) * kChunkBytes;
+    auto issue_read = [&](auto qc) {
+        constexpr int Qa = decltype(qc)::value;
+        lds_read_frag_asm<(Qa % kChunkQuads) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kChunkQuads) & 1]);
+    };
+    static_for<0, kPf>([&](auto ic) {
+        if constexpr (decltype(ic)::value < NQ) issue_read(ic);
+    });
 
-    // one accumulator register of a finished tile: LeakyReLU, then either keep fp32 (layer 8 -> heads)
-    // or split into fp16 hi/lo and drop into the fragment it feeds in the next layer
-    auto finish = [&](auto uc, auto rc, float v) {
-        constexpr int u = decltype(uc)::value;
+    // Epilogue of accumulator registers r, r+1 (r even) of output tile `ut` of a hidden layer, in three
+    // phases that the k-step interleaves with its three MFMAs (each 32-cycle MFMA hides ~4 plain VALU
+    // ops or ~2 conversions/moves; clustered they stall the matrix pipe):
+    //   A/B: y = LeakyReLU(acc + bias) for r / r+1     C: split hi/lo, pack fp16 pairs, store fragment dword
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto act = [&](float v) -> float {
+        const float av = alpha * v;
+        float y;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(v), "v"(av));
+        return y;
+    };
+    // bias = initial accumulator (C-in), loaded one tile ahead into the accumulator that tile will use
+    auto load_bias = [&](int off_bytes, f32x16& dst) {
+        static_for<0, 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const f32x4 b = lds_read4(cb_h + off_bytes + g * 32);
+            dst[4 * g + 0] = b[0]; dst[4 * g + 1] = b[1]; dst[4 * g + 2] = b[2]; dst[4 * g + 3] = b[3];
+        });
+    };
+    auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel) {
+        constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
-        if constexpr (BODY == BODY_LAST && u == kHTilesLast - 1) {
-            if constexpr (r == 0) sigma_raw = v;              // raw sigma: no activation (src/NeRF.py:336)
-        } else {
-            const float av = alpha * v;
-            float y;
-            asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(v), "v"(av));
-            if constexpr (BODY == BODY_LAST) {
-                xc[u * 16 + r] = y;
-            } else {
-                const _Float16 hi = (_Float16)y;
-                const _Float16 lo = (_Float16)(y - (float)hi);
-                constexpr int n = 2 * u + (r >> 3), e = r & 7;
-                if constexpr (BODY == BODY_PE || u == NU - 1) { xh[n][e] = hi; xl[n][e] = lo; }   // in place
-                else { nh[n][e] = hi; nl[n][e] = lo; }
-            }
-        }
+        constexpr int n = 2 * ut + (r >> 3), e = r & 7;
+        float h0, l0, h1, l1;
+        split_trunc(y0, h0, l0);
+        split_trunc(y1, h1, l1);
+        const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);   // whole-register writes
+        if constexpr (decltype(dest_sel)::value) { xh[n][e >> 1] = ph; xl[n][e >> 1] = pl; }
+        else { nh[n][e >> 1] = ph; nl[n][e >> 1] = pl; }
     };
 
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        f32x16& acc = (u & 1) ? acc1 : acc0;
-        f32x16& prv = (u & 1) ? acc0 : acc1;
-        static_for<0, 4>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const f32x4 b = lds_read4(cb_h + bias_off_bytes + (u * 32 + g * 8) * 4);
-            acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
-        });
+        f32x16& acc = accs[u & 3];
+        f32x16& prv = accs[(u + 3) & 3];
+        f32x16& nxt = accs[(u + 1) & 3];
+        if constexpr (u == 0 && !PENDING) load_bias(bias_off_bytes, acc);   // first layer of a tile: exposed once
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             f32x4 araw[2];
@@ -101,68 +158,101 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 constexpr int t = decltype(tc)::value;
                 constexpr int Q = u * QPU + 2 * n + t;
                 constexpr int left = NQ - Q;
+                if constexpr (Q % kChunkQuads == 0 && Q > 0) p.ck += 1;
                 if constexpr (Q % kChunkQuads == 8) pipe_sync(p, left <= 6);
                 if constexpr (Q % kChunkQuads == 10 && left + 2 > 6) pipe_piece(p, 1);
                 if constexpr (Q % kChunkQuads == 12 && left + 4 > 6) pipe_piece(p, 2);
                 if constexpr (Q % kChunkQuads == 14 && left + 6 > 6) pipe_piece(p, 3);
-                araw[t] = a_nx;
-                if constexpr (Q + 1 < NQ) {
-                    if constexpr ((Q + 1) % kChunkQuads == 0) {
-                        p.ck += 1;
-                        rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
-                    }
-                    a_nx = lds_read4(rd + ((Q + 1) % kChunkQuads) * kQuadBytes);
+                // quad Q has landed once at most the kPf-1 younger fragment reads are outstanding
+                lds_wait_frag_asm<(NQ - Q >= kPf ? kPf - 1 : NQ - Q - 1)>(pf[Q % kPf]);
+                araw[t] = pf[Q % kPf];
+                // chunk ck+1 is complete for every wave once this chunk's sync (quad 8) has passed, so a
+                // lookahead of 4 quads never reads ahead of a sync it depends on
+                if constexpr (Q + kPf < NQ) {
+                    constexpr int Qn = Q + kPf;
+                    if constexpr (Qn % kChunkQuads == 0)   // first read of a new chunk: point its base at the slot
+                        rdbase[(Qn / kChunkQuads) & 1] = lane16 + (uint32_t)((ck0 + Qn / kChunkQuads) & (kRingChunks - 1)) * kChunkBytes;
+                    issue_read(std::integral_constant<int, Qn>{});
                 }
             });
             const h8 a_hi = __builtin_bit_cast(h8, araw[0]);
             const h8 a_lo = __builtin_bit_cast(h8, araw[1]);
-            h8 b_hi, b_lo;
-            if constexpr (BODY == BODY_PE) { b_hi = peh[n]; b_lo = pel[n]; }
-            else if constexpr (BODY == BODY_HID) { b_hi = xh[n]; b_lo = xl[n]; }
+            frag4 bh_, bl_;
+            if constexpr (BODY == BODY_PE) { bh_ = peh[n]; bl_ = pel[n]; }
+            else if constexpr (BODY == BODY_HID) { bh_ = xh[n]; bl_ = xl[n]; }
             else if constexpr (BODY == BODY_SKIP) {
-                if constexpr (n < kHStepsPE) { b_hi = peh[n]; b_lo = pel[n]; }
-                else { b_hi = xh[n - kHStepsPE]; b_lo = xl[n - kHStepsPE]; }
+                if constexpr (n < kHStepsPE) { bh_ = peh[n]; bl_ = pel[n]; }
+                else { bh_ = xh[n - kHStepsPE]; bl_ = xl[n - kHStepsPE]; }
             } else {
-                if constexpr (n < kHStepsHid) { b_hi = xh[n]; b_lo = xl[n]; }
-                else { b_hi = dh[n - kHStepsHid]; b_lo = dl[n - kHStepsHid]; }
+                if constexpr (n < kHStepsHid) { bh_ = xh[n]; bl_ = xl[n]; }
+                else { bh_ = dh[n - kHStepsHid]; bl_ = dl[n - kHStepsHid]; }
             }
-            // x*w ~= hi*hi + lo_w*hi_x + hi_w*lo_x  (small terms first)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            const h8 b_hi = __builtin_bit_cast(h8, bh_), b_lo = __builtin_bit_cast(h8, bl_);
+            // ---- which deferred epilogue work rides on this k-step (register pair `er` of tile `et`) ----
+            constexpr bool kPend = (u == 0) && PENDING && n < 8;           // previous layer's tile 7
+            constexpr bool kPrev = (u > 0) && BODY != BODY_PE && n < 8;    // this layer's previous tile
+            constexpr bool kEpi = kPend || kPrev;
+            constexpr int et = kPend ? 7 : (u > 0 ? u - 1 : 0);
+            constexpr int er = 2 * (n < 8 ? n : 0);
+            constexpr bool kXc = BODY == BODY_LAST && kPrev;               // layer 8: fp32 for the rgb head
+            float y0 = 0.f, y1 = 0.f;
+
+            // x*w ~= hi_w*lo_x + lo_w*hi_x + hi_w*hi_x, on top of C-in = bias
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+            if constexpr (kEpi) y0 = act(prv[er]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            if constexpr (kEpi) y1 = act(prv[er + 1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
-            // deferred epilogue of the previous tile, dealt out over this tile's k-steps
-            // (2 registers per k-step: done by step 7, before the copy-back below needs fragments 12/13)
-            constexpr int kEpi = NSTEP >= 8 ? 2 : (16 + NSTEP - 1) / NSTEP;
-            if constexpr (u > 0) {
-                static_for<0, kEpi>([&](auto ic) {
-                    constexpr int r = n * kEpi + decltype(ic)::value;
-                    if constexpr (r < 16) finish(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, prv[r]);
+            if constexpr (kEpi) {
+                if constexpr (kXc) { xc[et * 16 + er] = y0; xc[et * 16 + er + 1] = y1; }
+                else if constexpr (kPend) store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{});
+                else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, er>{}, y0, y1, std::false_type{});
+            }
+            if constexpr (u == 0 && PENDING) {
+                // previous layer's tile 6 sits complete in nh/nl[12..13]; its k-steps are long retired
+                if constexpr (n == 8) { xh[12] = nh[12]; xl[12] = nl[12]; }
+                if constexpr (n == 9) { xh[13] = nh[13]; xl[13] = nl[13]; }
+            }
+            // preload the bias of the NEXT tile (or of the next layer's tile 0: the layers' biases are
+            // contiguous in the constant region) into the accumulator it will use -- free since 2 tiles
+            if constexpr (n == (NSTEP >= 12 ? 10 : 0)) {
+                if constexpr (u + 1 < NU) load_bias(bias_off_bytes + (u + 1) * 128, nxt);
+                else if constexpr (BODY != BODY_LAST) load_bias(bias_off_bytes + 8 * 128, nxt);
+            }
+            // layer 0 has only 3 k-steps per tile: its epilogues go in one block per tile
+            if constexpr (BODY == BODY_PE && u > 0 && n == 0) {
+                static_for<0, 8>([&](auto pc) {
+                    constexpr int r = 2 * decltype(pc)::value;
+                    const float z0 = act(prv[r]), z1 = act(prv[r + 1]);
+                    if constexpr (u - 1 <= 5) store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::true_type{});
+                    else store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::false_type{});
                 });
             }
-            // last tile of an in-place layer: fragments of x-in die as their k-step is consumed
+            // last tile of an in-place layer: fragment m-1 of x-in died with k-step m-1; tiles 0..5 of
+            // the new activations (fragments 0..11) are complete by now
             if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && u == NU - 1) {
                 constexpr int m = BODY == BODY_SKIP ? n - kHStepsPE : n;
-                if constexpr (m >= 1 && m - 1 < 14) { xh[m - 1] = nh[m - 1]; xl[m - 1] = nl[m - 1]; }
+                if constexpr (m >= 1 && m - 1 < 12) { xh[m - 1] = nh[m - 1]; xl[m - 1] = nl[m - 1]; }
             }
         });
     });
-    {
-        f32x16& last = ((NU - 1) & 1) ? acc1 : acc0;
-        static_for<0, 16>([&](auto rc) {
-            finish(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
-        });
+    if constexpr (BODY == BODY_LAST) {
+        // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
+        sigma_raw = accs[(NU - 1) & 3][0];
     }
     if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, true);
     p.ck += 1;
 }
 
 // fp32 values -> fp16 hi / lo fragments
-__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+__device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(v[e] - (float)h);
+    for (int e = 0; e < 8; e += 2) {
+        float h0, l0, h1, l1;
+        split_trunc(v[e], h0, l0);
+        split_trunc(v[e + 1], h1, l1);
+        hi[e >> 1] = pack_h2(h0, h1);
+        lo[e >> 1] = pack_h2(l0, l1);
     }
 }
 
@@ -204,11 +294,15 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    h8 xh[16], xl[16], nh[14], nl[14], peh[3], pel[3], dh[2], dl[2];
+    frag4 xh[16], xl[16], nh[14], nl[14], peh[3], pel[3], dh[2], dl[2];
+    f32x16 accs[4];
     float xc[64];
     float sigma_raw = 0.f;
 
+    unsigned long long t0 = 0, t1 = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)t0; (void)t1; (void)acc_t;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        STAMP(t0);
         const long long m = tile * 128 + wave * 32 + j;
         const bool valid = m < a.M;
         const long long mm = valid ? m : a.M - 1;
@@ -262,15 +356,21 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
             split8(t8, dh[n], dl[n]);
         }
 
-        layer_body_h<BODY_PE>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        STAMP(t1); acc_t[0] += t1 - t0;
+        layer_body_h<BODY_PE, false>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
-            if (l == 4)
-                layer_body_h<BODY_SKIP>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
-            else
-                layer_body_h<BODY_HID>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            if (l == 4) {
+                layer_body_h<BODY_SKIP, true>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
+            } else {
+                layer_body_h<BODY_HID, true>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
+            }
         }
-        layer_body_h<BODY_LAST>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        layer_body_h<BODY_LAST, true>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        STAMP(t1); acc_t[4] += t1 - t0;
 
         // rgb head (128 -> 3) on the VALU in fp32
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -299,7 +399,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
             out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = sigma_raw;
             *reinterpret_cast<f32x4*>(a.raw + m * 4) = out;
         }
+        STAMP(t0); acc_t[5] += t0 - t1; acc_t[6] += 1;
     }
+#ifdef NERF_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) g_stamps_h[i] = acc_t[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -309,6 +414,13 @@ void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream) {
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
     hipLaunchKernelGGL(mlp_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
+
+#ifdef NERF_STAMPS
+extern "C" void nerf_debug_read_stamps_h(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_h), sizeof(unsigned long long) * 16);
+}
+#endif
 
 void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_kernel),
