@@ -45,11 +45,13 @@ def sphere_matrix(radius, x_rot, y_rot, z_rot):
 def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
     """Oracle ("port") on the host cores, on a bounded sample of the same frame."""
     from oracle import nerf_oracle as O
+    # the GPU box shows every host core but a 1-GPU job owns a 16-core share: pin BLAS to that
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
     except Exception:
-        threads = os.cpu_count() or 1
+        limiter = None
     coarse, fine = O.unpack_blob(blob_c), O.unpack_blob(blob_f)
     dirs = O.get_rays_directions(H, W, FOV, c2w).reshape(-1, 4)
     orig = np.broadcast_to(c2w[:, 3], dirs.shape).astype(np.float32)
@@ -66,6 +68,8 @@ def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
     n = int(min(16384, max(512, 256 * seconds_budget / max(t_small, 1e-3))))
     n = (n // 256) * 256
     t = run(n)
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {"value": n / t, "unit": "rays/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} rays of the same 256x256 frame (64+128 samples), numpy fp32 + OpenBLAS, "
                       f"{t:.1f} s; CPU restatement of the reference algorithm (not TensorFlow)"}
@@ -76,7 +80,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
+                    help="arithmetic of the 256-wide contractions: f16x3 = 3-pass split-fp16 MFMA with fp32 accumulate "
+                         "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,9 +96,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
+    # BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import nerf_and_dietnerf_amd as N
 
@@ -101,7 +113,7 @@ def main():
                "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
                "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
     model = N.NeRF(net_cfg, {"n_render_samples_coarse": SC, "n_render_samples_fine": SF}, NEAR, FAR,
-                   device=local_rank, precision=args.precision)
+                   device=dev_index, precision=args.precision)
     model.set_weights(blob_c, blob_f)
     model.ctx.use_torch_stream()
     c2w = sphere_matrix(1.0, -30.0, 45.0, 0.0)
@@ -134,10 +146,30 @@ def main():
     mlp_ms, n_launch, n_rows = model.ctx.read_timing()
     model.ctx.enable_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(img).all()) and tuple(img.shape[-1:]) == (3,)
+
+    # the exact-fp32 mode of the same step, timed briefly beside the headline mode (N=1 only)
+    other = None
+    if world == 1 and args.precision == "f16x3":
+        model.ctx.set_precision("fp32")
+        step(0)
+        sync()
+        model.ctx.enable_timing(True)
+        t1 = time.perf_counter()
+        for i in range(3):
+            step(i)
+        sync()
+        e32 = time.perf_counter() - t1
+        ms32, nl32, rows32 = model.ctx.read_timing()
+        model.ctx.enable_timing(False)
+        model.ctx.set_precision("f16x3")
+        a32 = rows32 * FLOPS_PER_ROW / (ms32 * 1e-3) / 1e12
+        other = {"dtype": "f32", "value": total * 3 / e32, "unit": "rays/s", "steps": 3,
+                 "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel", "achieved": a32, "peak": PEAK_TFLOPS["f32"],
+                              "unit": "TFLOP/s", "frac": a32 / PEAK_TFLOPS["f32"]}}
 
     if rank == 0:
         value = total * args.steps / elapsed
@@ -153,17 +185,22 @@ def main():
             "metric": "rays/sec (coarse+fine) at 256x256, 64 coarse + 128 fine samples",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic (random-init Glorot weights, sphere pose, "
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == "f32" else "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
+            "data": "synthetic (random-init Glorot weights, sphere pose, "
                                                           "on-device Philox draws)",
             "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine (BASELINE configs[1]); contractions in " + ("exact fp32 MFMA" if dtype == "f32" else "3-pass split-fp16 MFMA, fp32 accumulate"),
                        "rays_per_step": total, "mlp_rows_per_ray": SC + SC + SF,
                        "parallelism": f"ray-sharded x{world}, one all-gather of RGB per frame"},
             "roofline": {"bound": "mfma", "kernel": ("mlp_fp32_kernel" if dtype == "f32" else "mlp_f16x3_kernel") + " (fused PE + 11-layer MLP)",
                          "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                         "frac": ach / PEAK_TFLOPS[dtype], "traffic": traffic,
+                         "frac": ach / PEAK_TFLOPS[dtype], "frac_vs_fp32_matrix_peak": ach / PEAK_TFLOPS["f32"],
+                         "mfma_passes_per_product": 1 if dtype == "f32" else 3, "traffic": traffic,
                          "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),
                          "flops_per_row": FLOPS_PER_ROW, "rows": int(n_rows)},
         }
+        if other is not None:
+            out["fp32_exact_mode"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
         print(json.dumps(out), flush=True)

@@ -25,9 +25,12 @@ def gather_slabs(local, total_rays: int, group=None):
     if local.shape[0] < per:
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()            # rehearsal on one GPU box: gloo has no CUDA all-gather
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out[:total_rays]
+    return out[:total_rays].to(dev)
 
 
 def render_image_sharded(model, c2w, fov, h, w, group=None, rgb_only=True, **kw):

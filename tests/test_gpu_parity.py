@@ -314,3 +314,64 @@ def test_f16x3_psnr_and_large_inputs(nerf16, golden_ckpt, oracle, nets):
     ref = oracle.model_predict(nets[1], pts, view)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_f16x3_matches_fp32_mode_full_size(nerf, golden_vec, oracle):
+    """Full 256x256 frame: the fast mode against the exact-fp32 mode of the same library (device vs device)."""
+    c2w = oracle.get_sphere_matrix(1.0, -30.0, 45.0, 0.0).astype(np.float32)
+    nerf.ctx.set_bounds(2.0 / 3.0, 5.0 / 3.0)
+    try:
+        ref = nerf.render_image(c2w, 0.6911112, 256, 256, seed=5, rgb_only=True)[0]
+        nerf.ctx.set_precision("f16x3")
+        got = nerf.render_image(c2w, 0.6911112, 256, 256, seed=5, rgb_only=True)[0]
+        err = np.abs(got - ref).max()
+        print("f16x3 vs fp32 mode, 65536 rays: max-abs rgb diff", err)
+        assert err <= RGB_TOL
+    finally:
+        nerf.ctx.set_precision("fp32")
+        nerf.ctx.set_bounds(float(golden_vec["near"]), float(golden_vec["far"]))
+
+
+# ---------------------------------------------------------------- other BASELINE configs as parity cases
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_config4_dietnerf_shape(nerf, nets, oracle, golden_vec, precision):
+    """DietNeRF consistency render shape (src/DietNeRF.py:215-218): 150x150 image, 55 coarse + 55 fine
+    (sample rows are NOT a multiple of the 32-row wave tile, so tiles straddle rays), batch 2048."""
+    c2w, fov = golden_vec["c2w"], float(golden_vec["fov"])
+    nerf.ctx.set_precision(precision)
+    try:
+        out = nerf.render_image(c2w, fov, 150, 150, batch_size_input=2048, n_render_samples_c=55,
+                                n_render_samples_f=55, seed=9)
+        assert out[0].shape == (150, 150, 3) and out[5].shape == (150, 150, 110)
+        pick = np.linspace(0, 150 * 150 - 1, 48).astype(np.int64)
+        dirs = oracle.get_rays_directions(150, 150, fov, c2w).reshape(-1, 4)[pick]
+        orig = np.broadcast_to(c2w[:, 3], dirs.shape).astype(np.float32)
+        ref = oracle.render(nets[0], nets[1], orig, dirs, float(golden_vec["near"]), float(golden_vec["far"]),
+                            oracle.philox_uniform(9, pick.astype(np.uint64), 55, 0),
+                            oracle.philox_uniform(9, pick.astype(np.uint64), 55, 1))
+        assert np.abs(out[0].reshape(-1, 3)[pick] - ref[0]).max() <= RGB_TOL
+    finally:
+        nerf.ctx.set_precision("fp32")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_config5_many_fine_samples(nerf, nets, oracle, golden_vec, precision):
+    """800x800-style sampling (64 coarse + 256 fine => 320-sample fine pass) on a slab of rays."""
+    c2w, fov = golden_vec["c2w"], float(golden_vec["fov"])
+    h = w = 800
+    nerf.ctx.set_precision(precision)
+    try:
+        begin, count = 800 * 400 + 300, 96           # a slab in the middle of the image
+        out = nerf.render_image(c2w, fov, h, w, n_render_samples_c=64, n_render_samples_f=256, seed=2,
+                                ray_begin=begin, ray_count=count)
+        assert out[0].shape == (count, 3) and out[5].shape == (count, 320)
+        pick = np.arange(begin, begin + count)
+        dirs = oracle.get_rays_directions(h, w, fov, c2w).reshape(-1, 4)[pick]
+        orig = np.broadcast_to(c2w[:, 3], dirs.shape).astype(np.float32)
+        ref = oracle.render(nets[0], nets[1], orig, dirs, float(golden_vec["near"]), float(golden_vec["far"]),
+                            oracle.philox_uniform(2, pick.astype(np.uint64), 64, 0),
+                            oracle.philox_uniform(2, pick.astype(np.uint64), 256, 1))
+        assert np.abs(out[0] - ref[0]).max() <= RGB_TOL
+        assert np.all(np.diff(out[5], axis=-1) >= 0)
+    finally:
+        nerf.ctx.set_precision("fp32")

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main(tag, dtype, kernel_substr):
     vals = collections.defaultdict(list)
-    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}*", "*_counter_collection.csv"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}[abc]", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
                 vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -41,7 +41,7 @@ def main(tag, dtype, kernel_substr):
         if "SQ_WAVE_CYCLES" in avg and "SQ_WAIT_ANY" in avg:
             out["wait_any_frac"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", f"{tag}_{dtype}_pmc_summary.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", f"r1_{dtype}_pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = json.load(open(tf)) if os.path.exists(tf) else {}
