@@ -11,6 +11,7 @@ from ._lib import (NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FIN
 from .render import (Context, NeRF, NetHandle, default_context, get_rays_directions, get_size_of_splits,
                      get_z_vals_from_prob_dist_func, get_z_values, model_predict, positional_encoding_for_views,
                      positional_encoding_for_xyz, ray_marching, render_rays, split_to_batches)
+from .keras_h5 import load_nerf_checkpoint, read_keras_weights
 from .sharding import gather_slabs, ray_slab, render_image_sharded
 from .weights import blob_size, glorot_blob, layer_shapes
 

@@ -333,6 +333,19 @@ class NeRF:
         if fine is not None and self.model_fine is not None:
             self.ctx.load_weights(NERF_NET_FINE, fine)
 
+    def load_weights(self, path) -> None:
+        """Keras ``model.load_weights(path)`` for the reference's ``NeRF_model_epoch_XXX.h5`` files
+        (src/ExecutionRun.py:228-231) -- parsed by the built-in pure-Python HDF5 reader."""
+        from .keras_h5 import load_nerf_checkpoint
+        coarse, fine = load_nerf_checkpoint(str(path))
+        self.set_weights(coarse, fine)
+
+    @staticmethod
+    def get_nerf_model_path(save_location, epoch_number: int):
+        """src/NeRF.py:342-351."""
+        from pathlib import Path
+        return Path(save_location) / "saved_weights" / "NeRF_model_epoch_{:03}.h5".format(epoch_number)
+
     def call(self, inputs, training=None, mask=None):
         rays_orig, rays_dirs = inputs
         return self.render(rays_orig, rays_dirs)[0]
