@@ -62,3 +62,48 @@ def test_sharded_assembly_world2(h, w, rgb_only):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _FakeVideoModel:
+    """render_image(..., seed=s, want_depth=True) -> per-frame outputs that encode the seed."""
+
+    class _Ctx:
+        class cfg:
+            device = 0
+    ctx = _Ctx()
+
+    def render_image(self, c2w, fov, h, w, seed=0, **kw):
+        base = torch.full((h, w), float(seed))
+        rgb = torch.stack([base, base + 0.25, base + 0.5], -1) + float(c2w[0, 3])
+        return (rgb, None, None, None, None, None, base * 2)
+
+
+def _video_worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_and_dietnerf_amd import video
+        poses = video.get_l_to_r_c2w_matrices(n_frames)
+        rgb, dep = video.render_video(_FakeVideoModel(), poses, 0.5, 4, 3, seed=10, equalize_depth=False,
+                                      shard_frames=True)
+        ok = rgb.shape == (n_frames, 4, 3, 3) and dep.shape == (n_frames, 4, 3)
+        for f in range(n_frames):
+            ok &= bool(np.allclose(rgb[f, ..., 0], 10 + f + poses[f, 0, 3])) and bool(np.allclose(dep[f], 2 * (10 + f)))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 2, 1])
+def test_video_frame_sharding_world2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_video_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
