@@ -86,6 +86,37 @@ __device__ __forceinline__ void pipe_sync(Pipe& p, bool all_pieces) {
     if (all_pieces) { pipe_piece(p, 1); pipe_piece(p, 2); pipe_piece(p, 3); }
 }
 
+// ---- generalised form: chunks of CQ quads (CQ KiB), ring of RING slots, CQ/4 pieces per wave ----
+// (the fp16 kernel runs 32 KiB chunks in a 4-slot ring: its 32-cycle MFMAs make a 16 KiB chunk last
+//  only ~770 cycles, and one s_barrier per chunk was costing it several per cent)
+template <int CQ>
+__device__ __forceinline__ void pipe_piece_t(Pipe& p, int j) {
+#if !(defined(NERF_DIAG) && NERF_DIAG == 2)
+    dma_piece(p.cur_src, p.voff + j * kQuadBytes, p.cur_dst + j * kQuadBytes);
+#endif
+}
+
+// Mid-chunk sync of chunk p.ck; issues piece 0 (the caller deals out the others, or passes
+// first_unplaced < CQ/4 to have pieces [first_unplaced, CQ/4) issued here because the body ends first).
+template <int CQ, int RING>
+__device__ __forceinline__ void pipe_sync_t(Pipe& p, int first_unplaced) {
+    constexpr int NPIECE = CQ / 4;
+#if defined(NERF_DIAG) && NERF_DIAG == 2
+    asm volatile("" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(NPIECE * (RING - 3)) : "memory");
+#if !(defined(NERF_DIAG) && NERF_DIAG == 1)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+#endif
+    p.cur_src = p.wbase + (size_t)p.src_next * (CQ * kQuadBytes);
+    p.cur_dst = kLdsRing + ((p.ck + RING - 1) & (RING - 1)) * (CQ * kQuadBytes) + p.wave_lds;
+    p.src_next = (p.src_next + 1 == p.n_chunks) ? 0 : p.src_next + 1;
+    pipe_piece_t<CQ>(p, 0);
+    for (int j = first_unplaced; j < NPIECE; ++j) pipe_piece_t<CQ>(p, j);
+}
+
 enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
 
 #ifdef NERF_STAMPS   // diagnostic build only: per-phase cycle sums of wave 0 of workgroup 0

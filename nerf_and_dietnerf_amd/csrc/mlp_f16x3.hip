@@ -52,11 +52,15 @@ constexpr int kHQpuHid = 2 * kHStepsHid;
 constexpr int kHQpuSkip = kHQpuPE + kHQpuHid;
 constexpr int kHQpuLast = kHQpuHid + 2 * kHStepsDir;
 constexpr int kHTilesLast = 5;    // 4 x 32 features of layer 8 + the sigma row
-constexpr int kHChunksPE = (8 * kHQpuPE + 15) / 16;          // 3
-constexpr int kHChunksHid = (8 * kHQpuHid) / 16;             // 16
-constexpr int kHChunksSkip = (8 * kHQpuSkip + 15) / 16;      // 19
-constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + 15) / 16;   // 12
-constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 130
+constexpr int kHCQ = 32;          // quads per chunk (32 KiB)
+constexpr int kHRing = 4;         // ring slots (128 KiB)
+constexpr int kHChunkBytes = kHCQ * kQuadBytes;
+constexpr int kHChunksPE = (8 * kHQpuPE + kHCQ - 1) / kHCQ;          // 2
+constexpr int kHChunksHid = (8 * kHQpuHid) / kHCQ;                   // 8
+constexpr int kHChunksSkip = (8 * kHQpuSkip + kHCQ - 1) / kHCQ;      // 10
+constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + kHCQ - 1) / kHCQ;   // 6
+constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 66
+static_assert(kHRing * kHChunkBytes == kRingBytes, "fp16 ring must fill the shared LDS carve");
 // constant region (floats)
 constexpr int kHConstBias = 0;        // 8 x 256
 constexpr int kHConstBias8 = 2048;    // 128
@@ -65,7 +69,7 @@ constexpr int kHConstWrgb = 2208;     // [3][128]
 constexpr int kHConstBHead = 2592;    // b_r, b_g, b_b, (unused)
 constexpr int kHConstFloats = 2608;
 
-static_assert(kHStreamChunks * (size_t)kChunkBytes == kStreamBytesF16, "stream size mismatch");
+static_assert(kHStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16, "stream size mismatch");
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
 
 // fp32 -> (hi, lo) with hi = the top 11 significand bits (exact in fp16) and lo = y - hi (exact in
@@ -100,15 +104,18 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     // AGPRs ("a"): plentiful here, legal as MFMA A operands, and never shuffled by the allocator between
     // the read and its wait.  LDS returns in order, so lgkmcnt(kPf-1) before quad Q's use means "Q has
     // landed" however many younger compiler-issued LDS reads are in flight (they only make it stricter).
-    constexpr int kPf = 4;
+#ifndef NERF_KPF
+#define NERF_KPF 4
+#endif
+    constexpr int kPf = NERF_KPF;
     f32x4 pf[kPf];
     const int ck0 = p.ck;   // chunk of quad 0 of this body; quad Q lives in chunk ck0 + Q/16
     uint32_t rdbase[2];     // LDS address of the ring slot of an even / odd chunk (refreshed as chunks retire)
-    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kRingChunks - 1)) * kChunkBytes;
-    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kRingChunks - 1)) * kChunkBytes;
+    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kHRing - 1)) * kHChunkBytes;
+    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kHRing - 1)) * kHChunkBytes;
     auto issue_read = [&](auto qc) {
         constexpr int Qa = decltype(qc)::value;
-        lds_read_frag_asm<(Qa % kChunkQuads) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kChunkQuads) & 1]);
+        lds_read_frag_asm<(Qa % kHCQ) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kHCQ) & 1]);
     };
     static_for<0, kPf>([&](auto ic) {
         if constexpr (decltype(ic)::value < NQ) issue_read(ic);
@@ -158,11 +165,15 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 constexpr int t = decltype(tc)::value;
                 constexpr int Q = u * QPU + 2 * n + t;
                 constexpr int left = NQ - Q;
-                if constexpr (Q % kChunkQuads == 0 && Q > 0) p.ck += 1;
-                if constexpr (Q % kChunkQuads == 8) pipe_sync(p, left <= 6);
-                if constexpr (Q % kChunkQuads == 10 && left + 2 > 6) pipe_piece(p, 1);
-                if constexpr (Q % kChunkQuads == 12 && left + 4 > 6) pipe_piece(p, 2);
-                if constexpr (Q % kChunkQuads == 14 && left + 6 > 6) pipe_piece(p, 3);
+                (void)left;
+                constexpr int qc = Q % kHCQ;        // position inside the chunk
+                if constexpr (qc == 0 && Q > 0) p.ck += 1;
+                if constexpr (qc == kHCQ / 2) {
+                    // pieces 1.. go out at quads +2, +4, ...; those that would fall past the body's end go now
+                    constexpr int room = (NQ - 1 - Q) / 2;                 // pieces that still find a quad
+                    pipe_sync_t<kHCQ, kHRing>(p, room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4);
+                }
+                if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) pipe_piece_t<kHCQ>(p, (qc - kHCQ / 2) / 2);
                 // quad Q has landed once at most the kPf-1 younger fragment reads are outstanding
                 lds_wait_frag_asm<(NQ - Q >= kPf ? kPf - 1 : NQ - Q - 1)>(pf[Q % kPf]);
                 araw[t] = pf[Q % kPf];
@@ -170,8 +181,8 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 // lookahead of 4 quads never reads ahead of a sync it depends on
                 if constexpr (Q + kPf < NQ) {
                     constexpr int Qn = Q + kPf;
-                    if constexpr (Qn % kChunkQuads == 0)   // first read of a new chunk: point its base at the slot
-                        rdbase[(Qn / kChunkQuads) & 1] = lane16 + (uint32_t)((ck0 + Qn / kChunkQuads) & (kRingChunks - 1)) * kChunkBytes;
+                    if constexpr (Qn % kHCQ == 0)   // first read of a new chunk: point its base at the slot
+                        rdbase[(Qn / kHCQ) & 1] = lane16 + (uint32_t)((ck0 + Qn / kHCQ) & (kHRing - 1)) * kHChunkBytes;
                     issue_read(std::integral_constant<int, Qn>{});
                 }
             });
@@ -240,7 +251,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
         sigma_raw = accs[(NU - 1) & 3][0];
     }
-    if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, true);
+    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_t<kHCQ, kHRing>(p, 1);
     p.ck += 1;
 }
 
@@ -277,20 +288,19 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
     p.src_next = 0;
     p.n_chunks = kHStreamChunks;
     p.wbase = reinterpret_cast<const char*>(a.wstream);
-    p.voff = wave * (4 * kQuadBytes) + lane * 16;
-    p.wave_lds = wave * (4 * kQuadBytes);
+    p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
+    p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
     __syncthreads();
+    // pipeline prologue: chunks 0 .. R-2 in flight, chunk 0 landed for everyone
 #pragma unroll
-    for (int c = 0; c < kRingChunks - 1; ++c) {
-        p.cur_src = p.wbase + (size_t)p.src_next * kChunkBytes;
-        p.cur_dst = kLdsRing + c * kChunkBytes + p.wave_lds;
+    for (int c = 0; c < kHRing - 1; ++c) {
+        p.cur_src = p.wbase + (size_t)p.src_next * kHChunkBytes;
+        p.cur_dst = kLdsRing + c * kHChunkBytes + p.wave_lds;
         p.src_next += 1;
-        dma_piece(p.cur_src, p.voff, p.cur_dst);
-        dma_piece(p.cur_src, p.voff + kQuadBytes, p.cur_dst + kQuadBytes);
-        dma_piece(p.cur_src, p.voff + 2 * kQuadBytes, p.cur_dst + 2 * kQuadBytes);
-        dma_piece(p.cur_src, p.voff + 3 * kQuadBytes, p.cur_dst + 3 * kQuadBytes);
+#pragma unroll
+        for (int j = 0; j < kHCQ / 4; ++j) dma_piece(p.cur_src, p.voff + j * kQuadBytes, p.cur_dst + j * kQuadBytes);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingChunks - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHCQ / 4) * (kHRing - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -495,7 +505,7 @@ void pack_weights_f16x3(const float* blob, void* stream_out, float* const_out) {
         const int NU = body == BODY_LAST ? kHTilesLast : 8;
         const int NSTEP = body == BODY_PE ? kHStepsPE : body == BODY_HID ? kHStepsHid
                           : body == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
-        uint16_t* b0 = base + chunk * (kChunkBytes / 2);
+        uint16_t* b0 = base + chunk * (kHChunkBytes / 2);
         for (int u = 0; u < NU; ++u)
             for (int n = 0; n < NSTEP; ++n)
                 for (int lane = 0; lane < 64; ++lane)
@@ -522,7 +532,7 @@ void pack_weights_f16x3(const float* blob, void* stream_out, float* const_out) {
                         b0[(q + 0) * (kQuadBytes / 2) + lane * 8 + e] = hi;
                         b0[(q + 1) * (kQuadBytes / 2) + lane * 8 + e] = lo;
                     }
-        chunk += (NU * NSTEP * 2 + kChunkQuads - 1) / kChunkQuads;
+        chunk += (NU * NSTEP * 2 + kHCQ - 1) / kHCQ;
     };
     emit_body(0, BODY_PE);
     for (int l = 1; l <= 3; ++l) emit_body(l, BODY_HID);

@@ -34,7 +34,7 @@ constexpr int kChunksSkip = (8 * kQpuSkip + 15) / 16;  // 19
 constexpr int kChunksLast = (4 * kQpuLast + 15) / 16;  // 9
 constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksLast;  // 127
 constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
-constexpr size_t kStreamBytesF16 = size_t(130) * kChunkBytes;   // f16x3 stream (mlp_f16x3.hip)
+constexpr size_t kStreamBytesF16 = size_t(66) * 32 * kQuadBytes;   // f16x3 stream: 66 chunks of 32 KiB (mlp_f16x3.hip)
 
 // ---- constant region (biases + head weights), floats ----
 constexpr int kConstBias = 0;                       // 8 x 256 hidden-layer biases (layers 0..7)

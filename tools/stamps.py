@@ -8,6 +8,10 @@ M = 128*256*64   # 64 tiles per workgroup
 rng = np.random.default_rng(0)
 xyz = rng.uniform(-1,1,(M,3)).astype(np.float32); d = rng.uniform(-1,1,(M,3)).astype(np.float32)
 ctx.model_predict(0, xyz, d)
+ctx.enable_timing(True)
+ctx.model_predict(0, xyz, d)
+ms, nl, rows = ctx.read_timing()
+print(f'wall: {ms:.3f} ms for {rows} rows -> {rows*1024304/ms/1e9:.1f} TFLOP/s algorithmic')
 out = (ctypes.c_ulonglong*16)()
 (N._lib.load().nerf_debug_read_stamps if prec == 'fp32' else N._lib.load().nerf_debug_read_stamps_h)(out)
 v = list(out)[:8]
