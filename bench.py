@@ -84,6 +84,9 @@ def main():
                     help="arithmetic of the 256-wide contractions: f16x3 = 3-pass split-fp16 MFMA with fp32 accumulate "
                          "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="1-GPU rehearsal of the per-rank work at N=<k>: render only rank 0's slab of a k-way split "
+                         "(no collective); the printed value is that slab's rays/s x k (an estimate, not a result)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +122,8 @@ def main():
     c2w = sphere_matrix(1.0, -30.0, 45.0, 0.0)
     total = H * W
     begin, count = N.ray_slab(total, rank, world)
+    if args.rehearse_world > 1 and world == 1:
+        begin, count = N.ray_slab(total, 0, args.rehearse_world)
 
     def step(seed):
         # whole-slab batch (the library's default); results do not depend on the batch size
@@ -150,10 +155,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(img).all()) and tuple(img.shape[-1:]) == (3,)
+    if args.rehearse_world > 1:
+        args.no_cpu_baseline = True
 
     # the exact-fp32 mode of the same step, timed briefly beside the headline mode (N=1 only)
     other = None
-    if world == 1 and args.precision == "f16x3":
+    if world == 1 and args.precision == "f16x3" and args.rehearse_world <= 1:
         model.ctx.set_precision("fp32")
         step(0)
         sync()
@@ -173,6 +180,8 @@ def main():
 
     if rank == 0:
         value = total * args.steps / elapsed
+        if args.rehearse_world > 1 and world == 1:
+            value = count * args.rehearse_world * args.steps / elapsed
         dtype = "f32" if args.precision == "fp32" else "f16x3"
         ach = (n_rows * FLOPS_PER_ROW) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         traffic = None

@@ -1,8 +1,13 @@
+#!/bin/bash
+# One GPU-box call: parity tests, the default bench line, an N=8 per-rank rehearsal, per-phase stamps,
+# rocprofv3 kernel stats and the PMC passes (separate --pmc passes, as MI355X_MICROARCH.md prescribes).
 set -o pipefail
 cd /root/repo
 mkdir -p gpurun_out
+timeout -k 10 400 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/pytest_gpu.log
 timeout -k 10 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc $?"; cat gpurun_out/bench_default.json
-BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 1 > gpurun_out/bench_gloo2.json 2> gpurun_out/bench_gloo2.err; echo "gloo2 rc $?"; tail -c 600 gpurun_out/bench_gloo2.json; tail -3 gpurun_out/bench_gloo2.err
+for k in 2 4 8; do timeout -k 10 200 python bench.py --rehearse-world $k --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('rehearse world $k: est rays/s', d['value'], 'ms/step', d['ms_per_step'])"; done
+if [ -f nerf_and_dietnerf_amd/lib/libnerf_st.so ]; then NERF_MI355_LIB=$PWD/nerf_and_dietnerf_amd/lib/libnerf_st.so timeout -k 10 100 python tools/stamps.py f16x3 2>&1 | tail -12; fi
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_r1f -o f16 --output-format csv -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /root/repo/gpurun_out/prof_r1f.log 2>&1; echo "prof rc $?"
 for mode in f16x3 fp32; do
