@@ -51,7 +51,7 @@ __global__ void raygen_kernel(const RaygenArgs a) {
     if (a.orig) reinterpret_cast<float4*>(a.orig)[t] = make_float4(a.c[3], a.c[7], a.c[11], a.c[15]);
 }
 
-void launch_raygen(const float*, const float c2w_host[16], float fov, int H, int W, long long ray_begin,
+void launch_raygen(const float c2w_host[16], float fov, int H, int W, long long ray_begin,
                    long long ray_count, float* orig, float* dirs, hipStream_t stream) {
     if (ray_count <= 0) return;
     RaygenArgs a;
@@ -105,35 +105,76 @@ __global__ __launch_bounds__(64 * kPdfWaves) void sample_pdf_kernel(
     const float* __restrict__ weights, const float* __restrict__ zin, long long N, int S, int Sf,
     const float* __restrict__ u, uint64_t seed, long long ray_base, float* __restrict__ z_new,
     float* __restrict__ z_merged) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long long ray = (long long)blockIdx.x * kPdfWaves + wave;
     if (ray >= N) return;   // whole wave exits; no block-level barrier is used below
-    const int per_wave = S + S + Sf + (S + Sf);
+    // per-wave LDS arrays, each padded to a multiple of 4 floats so the rank sorts can read float4
+    const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3, T = S + Sf, T4 = (T + 3) & ~3;
+    const int per_wave = S4 + S4 + Sf4 + T4;
     float* cdf = lds + wave * per_wave;   // first holds w, then pdf, then cdf
-    float* zc = cdf + S;
-    float* zn = zc + S;
-    float* za = zn + Sf;
+    float* zc = cdf + S4;
+    float* zn = zc + S4;
+    float* za = zn + Sf4;
     const float* wr = weights + ray * S;
     const float* zr = zin + ray * S;
-    for (int s = lane; s < S; s += 64) { cdf[s] = wr[s]; zc[s] = zr[s]; }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // canonical left-to-right sum, then cumsum of w / (sum + 1e-7)
-    if (lane == 0) {
+    // Canonical left-to-right sum and cumsum of w / (sum + 1e-7).  The order is sequential by definition,
+    // but only the additions are: every lane keeps its samples in registers, the running value is formed
+    // redundantly in all lanes from v_readlane broadcasts (no LDS round trip, no single-lane loop) and
+    // the divisions run 64 wide.  S <= 256 takes this path; longer rays fall back to a one-lane loop.
+    constexpr int kMaxChunks = 4;
+    if (S <= 64 * kMaxChunks) {
+        float wreg[kMaxChunks], creg[kMaxChunks];
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int s = lane + 64 * c;
+            wreg[c] = s < S ? wr[s] : 0.f;
+            if (s < S) zc[s] = zr[s];
+        }
         float sum = 0.f;
-        for (int s = 0; s < S; ++s) sum = __fadd_rn(sum, cdf[s]);
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int n = min(64, S - 64 * c);
+            for (int i = 0; i < n; ++i) sum = __fadd_rn(sum, __shfl(wreg[c], i));
+        }
         const float den = __fadd_rn(sum, 1e-7f);
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) {
-            acc = __fadd_rn(acc, __fdiv_rn(cdf[s], den));
-            cdf[s] = acc;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const float pdf = __fdiv_rn(wreg[c], den);
+            const int n = min(64, S - 64 * c);
+            creg[c] = 0.f;
+            for (int i = 0; i < n; ++i) {
+                acc = __fadd_rn(acc, __shfl(pdf, i));
+                if (lane == i) creg[c] = acc;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int s = lane + 64 * c;
+            if (s < S) cdf[s] = creg[c];
+        }
+    } else {
+        for (int s = lane; s < S; s += 64) { cdf[s] = wr[s]; zc[s] = zr[s]; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) {
+            float sum = 0.f;
+            for (int s = 0; s < S; ++s) sum = __fadd_rn(sum, cdf[s]);
+            const float den = __fadd_rn(sum, 1e-7f);
+            float acc = 0.f;
+            for (int s = 0; s < S; ++s) {
+                acc = __fadd_rn(acc, __fdiv_rn(cdf[s], den));
+                cdf[s] = acc;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < Sf; k += 64) {
+    const float kInf = __builtin_huge_valf();
+    for (int k = lane; k < Sf4; k += 64) {
+        if (k >= Sf) { zn[k] = kInf; continue; }   // padding never ranks below a real sample
         const float uu = u ? u[ray * Sf + k] : philox_uniform(seed, (uint64_t)(ray_base + ray), k, 1u);
         // searchsorted(cdf, uu, side='left'): first i with cdf[i] >= uu, in [0, S]
         int lo = 0, hi = S;
@@ -155,34 +196,38 @@ __global__ __launch_bounds__(64 * kPdfWaves) void sample_pdf_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // rank sort of the new depths (ties broken by index -> a permutation)
+    // rank sort (ties broken by index -> a permutation); every lane sweeps the array as float4 broadcasts
+    auto rank_of = [](const float* arr, int n4, float v, int k) -> int {
+        int rank = 0;
+        for (int i = 0; i < n4; i += 4) {
+            const float4 o = *reinterpret_cast<const float4*>(arr + i);
+            rank += (o.x < v || (o.x == v && i + 0 < k)) ? 1 : 0;
+            rank += (o.y < v || (o.y == v && i + 1 < k)) ? 1 : 0;
+            rank += (o.z < v || (o.z == v && i + 2 < k)) ? 1 : 0;
+            rank += (o.w < v || (o.w == v && i + 3 < k)) ? 1 : 0;
+        }
+        return rank;
+    };
     for (int k = lane; k < Sf; k += 64) {
         const float v = zn[k];
-        int rank = 0;
-        for (int i = 0; i < Sf; ++i) {
-            const float o = zn[i];
-            rank += (o < v || (o == v && i < k)) ? 1 : 0;
-        }
+        const int rank = rank_of(zn, Sf4, v, k);
         if (z_new) z_new[ray * Sf + rank] = v;
     }
     if (z_merged) {
-        const int T = S + Sf;
-        for (int k = lane; k < T; k += 64) za[k] = k < Sf ? zn[k] : zc[k - Sf];
+        for (int k = lane; k < T4; k += 64) za[k] = k < Sf ? zn[k] : (k < T ? zc[k - Sf] : kInf);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < T; k += 64) {
             const float v = za[k];
-            int rank = 0;
-            for (int i = 0; i < T; ++i) {
-                const float o = za[i];
-                rank += (o < v || (o == v && i < k)) ? 1 : 0;
-            }
-            z_merged[ray * T + rank] = v;
+            z_merged[ray * T + rank_of(za, T4, v, k)] = v;
         }
     }
 }
 
-size_t sample_pdf_lds_bytes(int S, int Sf) { return (size_t)kPdfWaves * (S + S + Sf + S + Sf) * sizeof(float); }
+size_t sample_pdf_lds_bytes(int S, int Sf) {
+    const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3, T4 = (S + Sf + 3) & ~3;
+    return (size_t)kPdfWaves * (S4 + S4 + Sf4 + T4) * sizeof(float);
+}
 
 void launch_sample_pdf(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
                        uint64_t seed, long long ray_base, float* z_new, float* z_merged, hipStream_t stream) {

@@ -125,7 +125,6 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     // phases that the k-step interleaves with its three MFMAs (each 32-cycle MFMA hides ~4 plain VALU
     // ops or ~2 conversions/moves; clustered they stall the matrix pipe):
     //   A/B: y = LeakyReLU(acc + bias) for r / r+1     C: split hi/lo, pack fp16 pairs, store fragment dword
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto act = [&](float v) -> float {
         const float av = alpha * v;
         float y;

@@ -14,9 +14,10 @@
 //     on the lane.  An accumulator register (after bias + LeakyReLU) IS the next layer's B operand
 //     for one k-step -- activations never leave the register file; the k order this implies is
 //     baked into the host-side weight packing.
-//   * weights (2.08 MB / net) stream L2 -> LDS through a 4 x 16 KiB ring by LDS-DMA
-//     (global_load_lds_dwordx4), one counted vmcnt + one s_barrier per 64 MFMAs, shared by the 4
-//     waves; A operands are read back with one ds_read_b128 per 4 MFMAs.
+//   * weights (2.08 MB / net) stream L2 -> LDS through an 8 x 16 KiB ring by LDS-DMA
+//     (global_load_lds_dwordx4, one piece per MFMA gap), one counted vmcnt + one s_barrier per 64
+//     MFMAs, shared by the 4 waves; A operands are read back with one ds_read_b128 per 4 MFMAs;
+//     output tiles are processed in pairs so two accumulator chains alternate.
 //   * heads (128->3, 280->1) on the VALU; positional encoding in-register with a Cody-Waite sincos.
 #include "mlp_common.h"
 

@@ -61,7 +61,7 @@ struct nerf_ctx {
     hipStream_t stream = nullptr;
     NetWeights net[2];
     // scratch arena (grow-only)
-    DevBuf b_orig, b_dirs, b_zc, b_zf, b_raw, b_wc, b_u0, b_u1, b_in0, b_in1, b_in2, b_in3;
+    DevBuf b_orig, b_dirs, b_zc, b_zf, b_raw, b_wc, b_u0, b_u1, b_in0, b_in1, b_in2;
     DevBuf b_out[7];
     // timing
     bool timing = false;
@@ -263,7 +263,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_orig, &c->b_dirs, &c->b_zc, &c->b_zf, &c->b_raw, &c->b_wc, &c->b_u0, &c->b_u1,
-                      &c->b_in0, &c->b_in1, &c->b_in2, &c->b_in3};
+                      &c->b_in0, &c->b_in1, &c->b_in2};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& b : c->b_out) if (b.p) (void)hipFree(b.p);
     for (auto& n : c->net) {
@@ -341,7 +341,7 @@ int nerf_get_rays_directions(nerf_ctx* c, const float* c2w, float fov, int32_t H
         if (int r = ensure(c, c->b_dirs, N * 16)) return r;
         d = (float*)c->b_dirs.p;
     }
-    launch_raygen(nullptr, c2w, fov, H, W, 0, N, nullptr, d, c->stream);
+    launch_raygen(c2w, fov, H, W, 0, N, nullptr, d, c->stream);
     HIP_OK(hipGetLastError());
     if (mem == NERF_MEM_HOST) {
         HIP_OK(hipMemcpyAsync(dirs, d, N * 16, hipMemcpyDeviceToHost, c->stream));
@@ -524,7 +524,7 @@ int nerf_render_image(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32
     // rays of the slab (origins are the broadcast translation column, src/NeRF.py:209)
     if (int r = ensure(c, c->b_orig, (size_t)N * 16)) return r;
     if (int r = ensure(c, c->b_dirs, (size_t)N * 16)) return r;
-    launch_raygen(nullptr, c2w, fov, H, W, ray_begin, N, (float*)c->b_orig.p, (float*)c->b_dirs.p, c->stream);
+    launch_raygen(c2w, fov, H, W, ray_begin, N, (float*)c->b_orig.p, (float*)c->b_dirs.p, c->stream);
     const float *duc = u_c, *duf = u_f;
     nerf_outputs dev = *outs;
     if (mem == NERF_MEM_HOST) {

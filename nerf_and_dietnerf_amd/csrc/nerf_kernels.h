@@ -76,7 +76,7 @@ void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 
 // aux_kernels.hip
-void launch_raygen(const float* unused, const float c2w_host[16], float fov, int H, int W,
+void launch_raygen(const float c2w_host[16], float fov, int H, int W,
                    long long ray_begin, long long ray_count, float* orig /*nullable*/, float* dirs,
                    hipStream_t stream);
 void launch_z_values(float near_b, float far_b, long long N, int S, const float* u, uint64_t seed,

@@ -94,7 +94,7 @@ def test_sample_pdf_edge_cases(nerf, oracle):
     np.testing.assert_array_equal(got, oracle.get_z_vals_from_prob_dist_func(w, z, u))
     assert np.all(np.diff(got, axis=-1) >= 0)
     # ragged shapes (DietNeRF: 55 coarse + 55 fine)
-    for (s, sf) in [(55, 55), (2, 3), (33, 200)]:
+    for (s, sf) in [(55, 55), (2, 3), (33, 200), (300, 64), (256, 8), (65, 1)]:   # 300 > 256: one-lane fallback
         z = np.sort(rng.uniform(0.5, 2.5, (9, s)).astype(np.float32), -1)
         w = rng.random((9, s), dtype=np.float32)
         u = rng.random((9, sf), dtype=np.float32)
