@@ -97,7 +97,8 @@ void launch_z_values(float near_b, float far_b, long long N, int S, const float*
 //   1. lane-parallel load of w,z; sequential (lane 0) sum and cumsum -> cdf  (canonical order)
 //   2. each lane: fine draws k = lane, lane+64, ...: binary search (searchsorted left), clip,
 //      1e-5 floor, lerp between bin midpoints
-//   3. rank sort of the Sf new depths; rank sort of concat(new, coarse) for the fine pass
+//   3. rank sort of the Sf new depths, then a binary-search merge with the (already increasing) coarse
+//      depths for the fine pass
 // ------------------------------------------------------------------------------------------------
 constexpr int kPdfWaves = 4;   // rays per workgroup
 
@@ -212,14 +213,39 @@ __global__ __launch_bounds__(64 * kPdfWaves) void sample_pdf_kernel(
         const float v = zn[k];
         const int rank = rank_of(zn, Sf4, v, k);
         if (z_new) z_new[ray * Sf + rank] = v;
+        za[rank] = v;                                   // za[0..Sf) = the new depths, sorted
     }
     if (z_merged) {
-        for (int k = lane; k < T4; k += 64) za[k] = k < Sf ? zn[k] : (k < T ? zc[k - Sf] : kInf);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < T; k += 64) {
-            const float v = za[k];
-            z_merged[ray * T + rank_of(za, T4, v, k)] = v;
+        // The stratified coarse depths are increasing by construction (UtilsCV.py:578-580); a caller of
+        // the stand-alone entry point may pass anything, so check before relying on it.
+        bool bad = false;
+        for (int s = lane; s + 1 < S; s += 64) bad |= zc[s + 1] < zc[s];
+        if (!__any(bad)) {
+            // sort(concat(new, coarse)) = merge of two sorted runs: output slot = own index + number of
+            // elements of the OTHER run that precede it, by binary search instead of an O(n^2) sweep
+            for (int k = lane; k < Sf; k += 64) {
+                const float v = za[k];
+                int lo = 0, hi = S;                      // # coarse depths < v
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] < v) lo = mid + 1; else hi = mid; }
+                z_merged[ray * T + k + lo] = v;
+            }
+            for (int j = lane; j < S; j += 64) {
+                const float v = zc[j];
+                int lo = 0, hi = Sf;                     // # new depths <= v
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (za[mid] <= v) lo = mid + 1; else hi = mid; }
+                z_merged[ray * T + j + lo] = v;
+            }
+        } else {
+            // general case: rank sort of the concatenation
+            for (int k = lane; k < T4; k += 64) if (k >= Sf) za[k] = k < T ? zc[k - Sf] : kInf;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < T; k += 64) {
+                const float v = za[k];
+                z_merged[ray * T + rank_of(za, T4, v, k)] = v;
+            }
         }
     }
 }

@@ -93,6 +93,13 @@ def test_sample_pdf_edge_cases(nerf, oracle):
     got = nerf.ctx.get_z_vals_from_prob_dist_func(w, z, sf, uniform_values=u)
     np.testing.assert_array_equal(got, oracle.get_z_vals_from_prob_dist_func(w, z, u))
     assert np.all(np.diff(got, axis=-1) >= 0)
+    # merged output: sorted coarse depths take the binary-search merge, unsorted ones the general rank sort
+    zs = z.copy(); zs[7] = zs[7, ::-1]; zs[8, 10] = zs[8, 40]
+    for zz in (z, zs):
+        gn, gm = nerf.ctx.get_z_vals_from_prob_dist_func(w, zz, sf, uniform_values=u, return_merged=True)
+        rn = oracle.get_z_vals_from_prob_dist_func(w, zz, u)
+        np.testing.assert_array_equal(gn, rn)
+        np.testing.assert_array_equal(gm, np.sort(np.concatenate([rn, zz], -1), -1))
     # ragged shapes (DietNeRF: 55 coarse + 55 fine)
     for (s, sf) in [(55, 55), (2, 3), (33, 200), (300, 64), (256, 8), (65, 1)]:   # 300 > 256: one-lane fallback
         z = np.sort(rng.uniform(0.5, 2.5, (9, s)).astype(np.float32), -1)
@@ -394,3 +401,38 @@ def test_render_video_loop(nerf, golden_vec):
         np.testing.assert_array_equal(dep[f], ref_depth)
     rgb2, dep2 = video.render_video(nerf, poses, fov, 16, 16, seed=40, loops=2)
     assert rgb2.shape[0] == 6 and dep2.min() >= 0.0 and dep2.max() <= 1.0
+
+
+def test_config5_full_800x800_properties(nerf, golden_vec):
+    """BASELINE config 5 at full size (640 000 rays x (64 + 320) rows) in the fast mode: size-independent
+    properties + slab invariance of an interior slab."""
+    c2w, fov = golden_vec["c2w"], float(golden_vec["fov"])
+    nerf.ctx.set_precision("f16x3")
+    try:
+        rgb, _, _, _, _, _, depth = nerf.render_image(c2w, fov, 800, 800, n_render_samples_c=64, n_render_samples_f=256,
+                                                     seed=4, rgb_only=True, want_depth=True)
+        assert rgb.shape == (800, 800, 3) and depth.shape == (800, 800)
+        assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and rgb.max() <= 1.0 + 1e-5
+        near, far = float(golden_vec["near"]), float(golden_vec["far"])
+        assert depth.min() >= 0.0 and depth.max() <= far + (far - near) / 64 + 1e-3   # sum w*z <= max z
+        slab = nerf.render_image(c2w, fov, 800, 800, n_render_samples_c=64, n_render_samples_f=256, seed=4,
+                                 rgb_only=True, ray_begin=123456, ray_count=5000)[0]
+        np.testing.assert_array_equal(slab, rgb.reshape(-1, 3)[123456:123456 + 5000])
+    finally:
+        nerf.ctx.set_precision("fp32")
+
+
+def test_config3_pose_sweep(nerf, golden_vec):
+    """BASELINE config 3 shape: a sweep of sphere poses at 256x256 through the video loop (fast mode)."""
+    from nerf_and_dietnerf_amd import video
+    poses = video.get_sphere_matrices(36)[::12][:4].copy()
+    poses[:, :3, 3] *= 1.5
+    nerf.ctx.set_precision("f16x3")
+    try:
+        rgb, dep = video.render_video(nerf, poses, float(golden_vec["fov"]), 256, 256, seed=100)
+        assert rgb.shape == (4, 256, 256, 3) and dep.shape == (4, 256, 256)
+        assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and rgb.max() <= 1.0 + 1e-5
+        assert dep.min() >= 0.0 and dep.max() <= 1.0                      # equalised depth
+        assert np.abs(rgb[0] - rgb[2]).max() > 1e-3                       # different poses, different frames
+    finally:
+        nerf.ctx.set_precision("fp32")
