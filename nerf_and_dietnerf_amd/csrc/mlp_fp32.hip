@@ -35,9 +35,9 @@ __device__ unsigned long long g_stamps[16];
 //   BODY_HID  : B = xin                      -> xin   (layers 1-3, 5-7; via xnext + staged copy-back)
 //   BODY_SKIP : B = [xpe, xin]               -> xin   (layer 4)
 //   BODY_LAST : B = [xin, xdir], 4 tiles     -> xc    (layer 8)
-template <int BODY>
+template <int BODY, bool PENDING>
 __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
-                                           uint32_t cb_h, int bias_off_bytes, float alpha,
+                                           uint32_t cb_h, int bias_off_bytes, float alpha, f32x16 (&accs)[4],
                                            float (&xin)[128], float (&xnext)[96], const float (&xpe)[17],
                                            const float (&xdir)[12], float (&xc)[64]) {
     // Output tiles are processed in PAIRS (u = 2P, 2P+1): the two accumulator chains alternate MFMA by
@@ -47,7 +47,9 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
     constexpr int QPU = BODY == BODY_PE ? kQpuPE : BODY == BODY_HID ? kQpuHid
                         : BODY == BODY_SKIP ? kQpuSkip : kQpuLast;
     constexpr int NQ = NP * 2 * QPU;
-    f32x16 accA0, accA1, accB0, accB1;   // pair P uses A* when P is even, B* when odd
+    // accs[0..1]: pair accumulators of even pairs, accs[2..3]: of odd pairs.  They live across layers:
+    // PENDING = the previous layer's last pair (tiles 6,7) still sits raw in accs[2..3] and is finished
+    // (in place, xin[96..127]) during this layer's first pair, so no epilogue is exposed at a layer end.
     uint32_t rd = lane16 + (uint32_t)(p.ck & (kRingChunks - 1)) * kChunkBytes;
     f32x4 a_nx = lds_read4(rd);          // A operands are fetched one quad ahead of their MFMAs
 
@@ -58,7 +60,7 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
     // canonicalising v_max per element.)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 alpha2 = {alpha, alpha};
-    auto store_act2 = [&](auto uc, auto rc, float v0, float v1) {
+    auto store_act2 = [&](auto uc, auto rc, float v0, float v1, auto dc) {
         constexpr int u = decltype(uc)::value;
         constexpr int r = decltype(rc)::value;   // even register index; handles r and r+1
 #ifdef NERF_DIAG_NOACT   // timing-only diagnostic: no activation math
@@ -70,26 +72,39 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
         asm("v_max_f32 %0, %1, %2" : "=v"(y0) : "v"(v0), "v"(av[0]));
         asm("v_max_f32 %0, %1, %2" : "=v"(y1) : "v"(v1), "v"(av[1]));
 #endif
-        if constexpr (BODY == BODY_PE) { xin[u * 16 + r] = y0; xin[u * 16 + r + 1] = y1; }
-        else if constexpr (BODY == BODY_LAST) { xc[u * 16 + r] = y0; xc[u * 16 + r + 1] = y1; }
-        else if constexpr (u >= 2 * NP - 2) { xin[u * 16 + r] = y0; xin[u * 16 + r + 1] = y1; }   // last pair: in place
+        constexpr int dst = decltype(dc)::value;   // 0: xin (in place)  1: xnext  2: xc
+        if constexpr (dst == 0) { xin[u * 16 + r] = y0; xin[u * 16 + r + 1] = y1; }
+        else if constexpr (dst == 2) { xc[u * 16 + r] = y0; xc[u * 16 + r + 1] = y1; }
         else { xnext[u * 16 + r] = y0; xnext[u * 16 + r + 1] = y1; }
+    };
+    // where tile u of THIS layer goes: layer 0 reads xpe only (in place), layer 8 feeds the heads,
+    // the in-place layers stage tiles 0..5 in xnext (tiles 6,7 are finished by the next layer)
+    auto dest_of = [](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (BODY == BODY_PE) return std::integral_constant<int, 0>{};
+        else if constexpr (BODY == BODY_LAST) return std::integral_constant<int, 2>{};
+        else if constexpr (u >= 6) return std::integral_constant<int, 0>{};
+        else return std::integral_constant<int, 1>{};
+    };
+    auto load_bias_pair = [&](int off_bytes, f32x16& d0, f32x16& d1) {
+        static_for<0, 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const f32x4 b0 = lds_read4(cb_h + off_bytes + g * 32);
+            const f32x4 b1 = lds_read4(cb_h + off_bytes + 128 + g * 32);
+            d0[4 * g + 0] = b0[0]; d0[4 * g + 1] = b0[1]; d0[4 * g + 2] = b0[2]; d0[4 * g + 3] = b0[3];
+            d1[4 * g + 0] = b1[0]; d1[4 * g + 1] = b1[1]; d1[4 * g + 2] = b1[2]; d1[4 * g + 3] = b1[3];
+        });
     };
 
     static_for<0, NP>([&](auto pc) {
         constexpr int P = decltype(pc)::value;
-        f32x16& acc0 = (P & 1) ? accB0 : accA0;
-        f32x16& acc1 = (P & 1) ? accB1 : accA1;
-        f32x16& prv0 = (P & 1) ? accA0 : accB0;   // previous pair's accumulators
-        f32x16& prv1 = (P & 1) ? accA1 : accB1;
-        // accumulators start as the bias of their 32 features (C-in of the first MFMA)
-        static_for<0, 4>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const f32x4 b0 = lds_read4(cb_h + bias_off_bytes + ((2 * P) * 32 + g * 8) * 4);
-            const f32x4 b1 = lds_read4(cb_h + bias_off_bytes + ((2 * P + 1) * 32 + g * 8) * 4);
-            acc0[4 * g + 0] = b0[0]; acc0[4 * g + 1] = b0[1]; acc0[4 * g + 2] = b0[2]; acc0[4 * g + 3] = b0[3];
-            acc1[4 * g + 0] = b1[0]; acc1[4 * g + 1] = b1[1]; acc1[4 * g + 2] = b1[2]; acc1[4 * g + 3] = b1[3];
-        });
+        f32x16& acc0 = accs[(P & 1) * 2 + 0];
+        f32x16& acc1 = accs[(P & 1) * 2 + 1];
+        f32x16& prv0 = accs[((P + 1) & 1) * 2 + 0];   // previous pair's accumulators (also the next pair's)
+        f32x16& prv1 = accs[((P + 1) & 1) * 2 + 1];
+        // accumulators start as the bias of their 32 features (C-in of the first MFMA); every pair but the
+        // very first of a tile gets it preloaded while the previous pair runs (below)
+        if constexpr (P == 0 && !PENDING) load_bias_pair(bias_off_bytes, acc0, acc1);
         static_for<0, QPU>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             f32x4 a4[2];
@@ -137,15 +152,28 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
             // hides only while each 64-cycle MFMA gap carries a few instructions, so it is dealt out
             // kEpi elements per quad-pair (8 MFMAs) instead of in one block.
             constexpr int kEpi = QPU >= 17 ? 1 : (16 + QPU - 2) / (QPU - 1);   // register PAIRS per q, q >= 1
-            if constexpr (P > 0 && q >= 1) {
+            if constexpr ((P > 0 || PENDING) && q >= 1) {
                 static_for<0, kEpi>([&](auto ic) {
                     constexpr int idx = (q - 1) * kEpi + decltype(ic)::value;   // 0..15 over the pair of tiles
                     if constexpr (idx < 16) {
                         constexpr int r = (idx & 7) * 2;
-                        if constexpr (idx < 8) store_act2(std::integral_constant<int, 2 * P - 2>{}, std::integral_constant<int, r>{}, prv0[r], prv0[r + 1]);
-                        else store_act2(std::integral_constant<int, 2 * P - 1>{}, std::integral_constant<int, r>{}, prv1[r], prv1[r + 1]);
+                        if constexpr (P == 0) {
+                            // previous layer's tiles 6,7: in place (their k-steps are first read at quad 24)
+                            if constexpr (idx < 8) store_act2(std::integral_constant<int, 6>{}, std::integral_constant<int, r>{}, prv0[r], prv0[r + 1], std::integral_constant<int, 0>{});
+                            else store_act2(std::integral_constant<int, 7>{}, std::integral_constant<int, r>{}, prv1[r], prv1[r + 1], std::integral_constant<int, 0>{});
+                        } else {
+                            if constexpr (idx < 8) store_act2(std::integral_constant<int, 2 * P - 2>{}, std::integral_constant<int, r>{}, prv0[r], prv0[r + 1], dest_of(std::integral_constant<int, 2 * P - 2>{}));
+                            else store_act2(std::integral_constant<int, 2 * P - 1>{}, std::integral_constant<int, r>{}, prv1[r], prv1[r + 1], dest_of(std::integral_constant<int, 2 * P - 1>{}));
+                        }
                     }
                 });
+            }
+            // the previous pair's accumulators are free once its epilogue is done (q = 16 at the latest):
+            // preload the bias of the NEXT pair -- or of the next layer's first pair: the layers' biases are
+            // contiguous in the constant region -- so that no chain starts on an LDS round trip
+            if constexpr (q == (QPU >= 20 ? 18 : QPU - 1)) {
+                if constexpr (P + 1 < NP) load_bias_pair(bias_off_bytes + (P + 1) * 256, prv0, prv1);
+                else if constexpr (BODY != BODY_LAST) load_bias_pair(bias_off_bytes + 1024, prv0, prv1);
             }
             // last pair of an in-place layer: tile t of xin is dead once its 4 quads (4t..4t+3) are
             // consumed; copy xnext back 4 registers per quad over the following 4 quads
@@ -162,13 +190,13 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
             }
         });
     });
-    {   // epilogue of the last pair
-        f32x16& l0 = ((NP - 1) & 1) ? accB0 : accA0;
-        f32x16& l1 = ((NP - 1) & 1) ? accB1 : accA1;
+    if constexpr (BODY == BODY_LAST) {   // layer 8 feeds the heads right away: finish its last pair here
+        f32x16& l0 = accs[((NP - 1) & 1) * 2 + 0];
+        f32x16& l1 = accs[((NP - 1) & 1) * 2 + 1];
         static_for<0, 8>([&](auto rc) {
             constexpr int r = decltype(rc)::value * 2;
-            store_act2(std::integral_constant<int, 2 * NP - 2>{}, std::integral_constant<int, r>{}, l0[r], l0[r + 1]);
-            store_act2(std::integral_constant<int, 2 * NP - 1>{}, std::integral_constant<int, r>{}, l1[r], l1[r + 1]);
+            store_act2(std::integral_constant<int, 2 * NP - 2>{}, std::integral_constant<int, r>{}, l0[r], l0[r + 1], std::integral_constant<int, 2>{});
+            store_act2(std::integral_constant<int, 2 * NP - 1>{}, std::integral_constant<int, r>{}, l1[r], l1[r + 1], std::integral_constant<int, 2>{});
         });
     }
     if constexpr (NQ % kChunkQuads != 0 && NQ % kChunkQuads <= 8) pipe_sync(p, true);
@@ -216,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
     asm volatile("" ::: "memory");
 
     float xin[128], xnext[96], xpe[17], xdir[12], xc[64];
+    f32x16 accs[4];
 
     unsigned long long t0 = 0, t1 = 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)acc_t;
@@ -257,19 +286,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
 
         // ---------------- the 9 MFMA layers ----------------
         STAMP(t1); acc_t[0] += t1 - t0;
-        layer_body<BODY_PE>(p, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        layer_body<BODY_PE, false>(p, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
         STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             if (l == 4) {
-                layer_body<BODY_SKIP>(p, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+                layer_body<BODY_SKIP, true>(p, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
                 STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
             } else {
-                layer_body<BODY_HID>(p, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+                layer_body<BODY_HID, true>(p, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
-        layer_body<BODY_LAST>(p, lane16, cb_h, kConstBias8 * 4, a.alpha, xin, xnext, xpe, xdir, xc);
+        layer_body<BODY_LAST, true>(p, lane16, cb_h, kConstBias8 * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
         STAMP(t1); acc_t[4] += t1 - t0;
 
         // ---------------- heads on the VALU ----------------
