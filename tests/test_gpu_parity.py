@@ -436,3 +436,27 @@ def test_config3_pose_sweep(nerf, golden_vec):
         assert np.abs(rgb[0] - rgb[2]).max() > 1e-3                       # different poses, different frames
     finally:
         nerf.ctx.set_precision("fp32")
+
+
+def test_coarse_only_model(golden_ckpt, golden_vec, oracle, nets):
+    """n_render_samples_fine == 0 => no fine network (src/NeRF.py:36-39,129): render() returns the coarse pass."""
+    import nerf_and_dietnerf_amd as N
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
+               "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
+    m = N.NeRF(net_cfg, {"n_render_samples_coarse": 64, "n_render_samples_fine": 0},
+               float(golden_ckpt["near"]), float(golden_ckpt["far"]))
+    assert m.model_fine is None
+    m.set_weights(golden_ckpt["blob_coarse"])
+    o, d = golden_vec["rays_orig"], golden_vec["rays_dirs"]
+    rgb, w, T, a, c, z = m.render(o, d, u_coarse=golden_vec["u_coarse"])
+    assert z.shape == (96, 64)
+    np.testing.assert_array_equal(z, golden_vec["z_coarse"])
+    assert np.abs(rgb - golden_vec["rgb_coarse"]).max() <= RGB_TOL
+    assert np.abs(w - golden_vec["weights_coarse"]).max() <= RGB_TOL
+    # per-call sample-count override (src/NeRF.py:126): 32 coarse samples
+    u32 = golden_vec["u_coarse"][:, :32].copy()
+    out = m.render(o, d, n_render_samples_c=32, u_coarse=u32)
+    ref = oracle.render(nets[0], None, o, d, float(golden_ckpt["near"]), float(golden_ckpt["far"]), u32, None)
+    assert out[5].shape == (96, 32) and np.abs(out[0] - ref[0]).max() <= RGB_TOL
+    m.ctx.close()
