@@ -479,16 +479,20 @@ int h_pe_row(int v, int h) {   // slot v (0..23) of lane half h -> row of the (3
     return -1;
 }
 int h_hid_row(int n, int e, int h) { const int t = n >> 1, s = n & 1; return 32 * t + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); }
-int h_dir_row(int v, int h) {   // slot v (0..15) -> row of the 24 dir features
-    if (v < 12) { const int c = v / 4, k = v % 4; return c * 8 + 2 * k + h; }
-    return -1;
+int h_dir_row(int v, int h, int n_angles) {   // slot v (0..15) -> row of the dir block (24 or 16 rows), -1 = pad
+    if (v >= 12) return -1;
+    const int c = v / 4, k = v % 4;
+    if (n_angles == 2) return c * 8 + 2 * k + h;
+    if (c == 1) return -1;                       // n_angles == 1: (x,z) only, src/UtilsCV.py:134-135
+    return (c == 0 ? 0 : 1) * 8 + 2 * k + h;
 }
 struct HLayer { const float* k; const float* b; int in, out; };
 }  // namespace
 
-void pack_weights_f16x3(const float* blob, void* stream_out, float* const_out) {
-    static const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
-                                      {256, 256}, {256, 256}, {280, 128}, {128, 3}, {280, 1}};
+void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out) {
+    const int kd = 256 + 8 * (n_angles + 1);
+    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
     HLayer L[11];
     size_t off = 0;
     for (int i = 0; i < 11; ++i) {
@@ -518,7 +522,7 @@ void pack_weights_f16x3(const float* blob, void* stream_out, float* const_out) {
                             else row = kXyzDim + h_hid_row(n - kHStepsPE, e, h);
                         } else {
                             if (n < kHStepsHid) row = h_hid_row(n, e, h);
-                            else { const int r = h_dir_row((n - kHStepsHid) * 8 + e, h); row = r < 0 ? -1 : kHidden + r; }
+                            else { const int r = h_dir_row((n - kHStepsHid) * 8 + e, h, n_angles); row = r < 0 ? -1 : kHidden + r; }
                         }
                         float w = 0.f;
                         if (row >= 0) {

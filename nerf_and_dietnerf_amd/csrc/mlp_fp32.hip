@@ -385,14 +385,23 @@ int pe_row(int s, int h) {
     return -1;
 }
 int hid_row(int s, int h) { const int t = s >> 4, r = s & 15; return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
-int dir_row(int s, int h) { const int c = s / 4, k = s % 4; return c * 8 + 2 * k + h; }
+// dir k-step s (0..11) = component c (x,y,z) x octave k -> row of the dir block of the kernel, or -1.
+// n_angles == 2: view dirs are (x,y,z) -> 24 rows.  n_angles == 1: the reference feeds only (x,z)
+// (src/UtilsCV.py:134-135) -> 16 rows; the kernel still encodes y, its weights are packed as zero.
+int dir_row(int s, int h, int n_angles) {
+    const int c = s / 4, k = s % 4;
+    if (n_angles == 2) return c * 8 + 2 * k + h;
+    if (c == 1) return -1;
+    return (c == 0 ? 0 : 1) * 8 + 2 * k + h;
+}
 
 struct Layer { const float* k; const float* b; int in, out; };
 }  // namespace
 
-void pack_weights_fp32(const float* blob, float* stream_out, float* const_out) {
-    static const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
-                                      {256, 256}, {256, 256}, {280, 128}, {128, 3}, {280, 1}};
+void pack_weights_fp32(const float* blob, int n_angles, float* stream_out, float* const_out) {
+    const int kd = 256 + 8 * (n_angles + 1);   // width of [hidden, dir_enc]: 280 (n_angles 2) or 272 (1)
+    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
     Layer L[11];
     size_t off = 0;
     for (int i = 0; i < 11; ++i) {
@@ -418,7 +427,8 @@ void pack_weights_fp32(const float* blob, float* stream_out, float* const_out) {
                         if (body == BODY_PE) row = pe_row(4 * q + e, h);
                         else if (body == BODY_HID) row = hid_row(4 * q + e, h);
                         else if (body == BODY_SKIP) row = q < kQpuPE ? pe_row(4 * q + e, h) : kXyzDim + hid_row(4 * (q - kQpuPE) + e, h);
-                        else row = q < kQpuHid ? hid_row(4 * q + e, h) : kHidden + dir_row(4 * (q - kQpuHid) + e, h);
+                        else if (q < kQpuHid) row = hid_row(4 * q + e, h);
+                        else { const int r = dir_row(4 * (q - kQpuHid) + e, h, n_angles); row = r < 0 ? -1 : kHidden + r; }
                         quad[lane * 4 + e] = row < 0 ? 0.f : L[layer].k[(size_t)row * L[layer].out + 32 * u + i];
                     }
             }
@@ -441,7 +451,10 @@ void pack_weights_fp32(const float* blob, float* stream_out, float* const_out) {
     for (int g = 0; g < 3; ++g)
         for (int h = 0; h < 2; ++h)
             for (int e = 0; e < 4; ++e)
-                const_out[kConstWsigD + (g * 2 + h) * 4 + e] = L[10].k[kHidden + dir_row(4 * g + e, h)];
+            {
+                    const int r = dir_row(4 * g + e, h, n_angles);
+                    const_out[kConstWsigD + (g * 2 + h) * 4 + e] = r < 0 ? 0.f : L[10].k[kHidden + r];
+                }
 }
 
 }  // namespace nerf

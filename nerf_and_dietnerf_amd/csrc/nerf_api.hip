@@ -99,9 +99,9 @@ int enter(nerf_ctx* c) {
 
 int check_cfg(const nerf_config* cfg) {
     if (!cfg) return fail("nerf_config is NULL");
-    if (cfg->n_angles != 2) {
-        if (cfg->n_angles == 0 || cfg->n_angles == 1)
-            return fail("n_angles_for_model=%d is not built yet (only 2; SURVEY.md section 2.1)", cfg->n_angles);
+    if (cfg->n_angles != 2 && cfg->n_angles != 1) {
+        if (cfg->n_angles == 0)
+            return fail("n_angles_for_model=0 (the xyz-only network, src/NeRF.py:248-288) is not built yet");
         return fail("n_angles_for_model should be 1 or 2.");   // message of src/UtilsCV.py:138
     }
     if (cfg->n_pos_enc_xyz != kLx || cfg->n_pos_enc_dir != kLd || cfg->hidden_dim != kHidden ||
@@ -226,8 +226,9 @@ const char* nerf_last_error(void) { return g_err.c_str(); }
 
 size_t nerf_blob_size(const nerf_config* cfg) {
     if (check_cfg(cfg)) return 0;
-    return 33 * 256 + 256 + 3 * (256 * 256 + 256) + 289 * 256 + 256 + 3 * (256 * 256 + 256) + 280 * 128 + 128 +
-           128 * 3 + 3 + 280 + 1;
+    const size_t kd = 256 + 8 * (size_t)(cfg->n_angles + 1);   // [hidden, dir_enc]: 280 or 272
+    return 33 * 256 + 256 + 3 * (256 * 256 + 256) + 289 * 256 + 256 + 3 * (256 * 256 + 256) + kd * 128 + 128 +
+           128 * 3 + 3 + kd + 1;
 }
 
 int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out) {
@@ -312,7 +313,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* blob, size_t n_floats
     if (n_floats != want) return fail("weight blob has %zu floats, expected %zu", n_floats, want);
     HIP_OK(hipSetDevice(c->cfg.device));
     std::vector<float> st(kStreamBytes / 4), cs(kConstFloats);
-    pack_weights_fp32(blob, st.data(), cs.data());
+    pack_weights_fp32(blob, c->cfg.n_angles, st.data(), cs.data());
     NetWeights& n = c->net[which];
     if (!n.stream) HIP_OK(hipMalloc((void**)&n.stream, kStreamBytes));
     if (!n.cst) HIP_OK(hipMalloc((void**)&n.cst, kConstBytes));
@@ -322,7 +323,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* blob, size_t n_floats
     // both operand formats are kept resident (2 x 2.1 MB per network) so precision can be switched per call
     std::vector<uint16_t> sth(kStreamBytesF16 / 2);
     std::vector<float> csh(kConstFloats);
-    pack_weights_f16x3(blob, sth.data(), csh.data());
+    pack_weights_f16x3(blob, c->cfg.n_angles, sth.data(), csh.data());
     if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16));
     if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
     HIP_OK(hipMemcpy(n.stream_h, sth.data(), kStreamBytesF16, hipMemcpyHostToDevice));

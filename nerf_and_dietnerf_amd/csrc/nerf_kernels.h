@@ -7,6 +7,8 @@
 namespace nerf {
 
 // ---- fixed network geometry of the fused kernel (all BASELINE configs) ----
+// n_angles_for_model 2 and 1 share the kernels: with 1 the y component of the view direction is still
+// encoded on device but its weight rows are packed as zeros (host side, pack_weights_*).
 constexpr int kLx = 5;           // n_pos_enc_dim_xyz
 constexpr int kLd = 4;           // n_pos_enc_view_dir
 constexpr int kHidden = 256;
@@ -68,12 +70,12 @@ struct MlpArgs {
 void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream);
 void mlp_fp32_set_attributes();
 // host-side packing of one network's blob (11 x (kernel(in,out), bias)) into stream + const
-void pack_weights_fp32(const float* blob, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
+void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
 
 // mlp_f16x3.hip
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream);
 void mlp_f16x3_set_attributes();
-void pack_weights_f16x3(const float* blob, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
+void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 
 // aux_kernels.hip
 void launch_raygen(const float c2w_host[16], float fov, int H, int W,

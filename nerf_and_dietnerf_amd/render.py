@@ -98,6 +98,7 @@ class Context:
         self.lib = _lib.load()
         if n_angles not in (0, 1, 2):
             raise Exception(f"{N_ANGLES_FOR_MODEL} should be 1 or 2.")   # src/UtilsCV.py:138
+        self.n_angles = n_angles
         self.cfg = NerfConfig(n_pos_enc_xyz, n_pos_enc_dir, n_angles, hidden_dim, last_hidden_dim,
                               leaky_relu_alpha, near, far, _PRECISIONS[precision], device)
         h = C.c_void_p()
@@ -227,6 +228,15 @@ class Context:
     def model_predict(self, which, xyz, view_dirs):
         arr = self._arrays(xyz, view_dirs)
         m = int(xyz.shape[0])
+        if self.cfg.n_angles == 1 and tuple(view_dirs.shape) == (m, 2):
+            # the reference hands (x, z) to the n_angles == 1 network (src/UtilsCV.py:134-135); the
+            # library takes full directions and ignores y through zero-packed weights
+            if arr.torch is not None and _is_torch(view_dirs):
+                z0 = arr.torch.zeros_like(view_dirs[:, :1])
+                view_dirs = arr.torch.cat([view_dirs[:, :1], z0, view_dirs[:, 1:]], dim=1)
+            else:
+                v = np.asarray(view_dirs, np.float32)
+                view_dirs = np.stack([v[:, 0], np.zeros(m, np.float32), v[:, 1]], axis=1)
         px, pv = arr.inp(xyz, (m, 3)), arr.inp(view_dirs, (m, 3))
         out, p = arr.out((m, 4))
         _lib.check(self.lib.nerf_model_predict(self.h, which, px, pv, m, p, arr.mem))

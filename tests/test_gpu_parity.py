@@ -460,3 +460,31 @@ def test_coarse_only_model(golden_ckpt, golden_vec, oracle, nets):
     ref = oracle.render(nets[0], None, o, d, float(golden_ckpt["near"]), float(golden_ckpt["far"]), u32, None)
     assert out[5].shape == (96, 32) and np.abs(out[0] - ref[0]).max() <= RGB_TOL
     m.ctx.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_n_angles_1_network(oracle, precision):
+    """n_angles_for_model == 1 (5 of the reference's configs): view dirs are (x, z) -> 16-dim encoding,
+    layers (272,128) and (272,1).  Same kernels; the y slots carry zero weights."""
+    import nerf_and_dietnerf_amd as N
+    near, far = 0.6, 2.4
+    ctx = N.Context(n_angles=1, near=near, far=far, precision=precision)
+    bc, bf = N.glorot_blob(3, n_angles=1), N.glorot_blob(4, n_angles=1)
+    assert bc.size == ctx.blob_size() == 513300
+    ctx.load_weights(0, bc); ctx.load_weights(1, bf)
+    coarse, fine = oracle.unpack_blob(bc, n_angles=1), oracle.unpack_blob(bf, n_angles=1)
+    rng = np.random.default_rng(2)
+    n = 40
+    o = np.concatenate([rng.uniform(-0.3, 0.3, (n, 3)), np.ones((n, 1))], 1).astype(np.float32)
+    d = np.concatenate([rng.uniform(-1, 1, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    uc, uf = rng.random((n, 64), dtype=np.float32), rng.random((n, 128), dtype=np.float32)
+    got = ctx.render(o, d, 64, 128, uc, uf)
+    ref = oracle.render(coarse, fine, o, d, near, far, uc, uf, n_angles=1)
+    assert np.abs(got[0] - ref[0]).max() <= RGB_TOL
+    # model_predict with the reference's (M,2) = (x,z) view directions
+    pts = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    v2 = rng.uniform(-1, 1, (300, 2)).astype(np.float32)
+    raw = ctx.model_predict(0, pts, v2)
+    rref = oracle.model_predict(coarse, pts, v2)
+    assert np.abs(raw - rref).max() <= 5e-5 * max(1.0, np.abs(rref).max())
+    ctx.close()
