@@ -488,3 +488,48 @@ def test_n_angles_1_network(oracle, precision):
     rref = oracle.model_predict(coarse, pts, v2)
     assert np.abs(raw - rref).max() <= 5e-5 * max(1.0, np.abs(rref).max())
     ctx.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_random_shapes_sweep(nerf, nets, oracle, golden_vec, precision):
+    """Ragged ray counts and sample counts (tiles straddling rays, partial last tile, tiny launches)."""
+    rng = np.random.default_rng(123)
+    near, far = float(golden_vec["near"]), float(golden_vec["far"])
+    o_all, d_all = golden_vec["rays_orig"], golden_vec["rays_dirs"]
+    nerf.ctx.set_precision(precision)
+    try:
+        for (n, sc, sf) in [(1, 2, 1), (3, 5, 7), (17, 33, 0), (64, 64, 128), (96, 7, 100), (50, 80, 31), (2, 64, 256)]:
+            idx = rng.integers(0, 96, n)
+            o, d = o_all[idx], d_all[idx]
+            uc = rng.random((n, sc), dtype=np.float32)
+            uf = rng.random((n, max(sf, 1)), dtype=np.float32)[:, :sf] if sf else None
+            got = nerf.ctx.render(o, d, sc, sf, uc, uf)
+            ref = oracle.render(nets[0], nets[1] if sf else None, o, d, near, far, uc, uf)
+            assert got[0].shape == (n, 3) and got[5].shape == (n, sc + sf)
+            assert np.abs(got[0] - ref[0]).max() <= RGB_TOL, (n, sc, sf)
+            assert np.mean(np.abs(got[5] - ref[5]) > 1e-5) < 5e-3, (n, sc, sf)
+    finally:
+        nerf.ctx.set_precision("fp32")
+
+
+def test_host_path_throughput_note(nerf, golden_vec, capsys):
+    """Not a bar: prints the PCIe-inclusive rate of the host-memory entry point for DESIGN.md."""
+    import time
+    c2w, fov = golden_vec["c2w"], float(golden_vec["fov"])
+    nerf.ctx.set_precision("f16x3")
+    try:
+        nerf.render_image(c2w, fov, 256, 256, seed=1, rgb_only=True)
+        t0 = time.perf_counter()
+        for i in range(5):
+            out = nerf.render_image(c2w, fov, 256, 256, seed=i, rgb_only=True)      # numpy in, numpy out
+        dt = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        for i in range(3):
+            full = nerf.render_image(c2w, fov, 256, 256, seed=i)                    # all six outputs to host
+        dt6 = (time.perf_counter() - t0) / 3
+        with capsys.disabled():
+            print(f"\n[host path] 256x256 rgb-only via host buffers: {dt * 1e3:.2f} ms/frame = {65536 / dt:.3e} rays/s; "
+                  f"all six outputs (353 MB D2H): {dt6 * 1e3:.1f} ms/frame = {65536 / dt6:.3e} rays/s")
+        assert out[0].shape == (256, 256, 3) and full[4].shape == (256, 256, 192, 3)
+    finally:
+        nerf.ctx.set_precision("fp32")
