@@ -533,3 +533,33 @@ def test_host_path_throughput_note(nerf, golden_vec, capsys):
         assert out[0].shape == (256, 256, 3) and full[4].shape == (256, 256, 192, 3)
     finally:
         nerf.ctx.set_precision("fp32")
+
+
+def test_c_abi_client(tmp_path, oracle):
+    """The boundary is a C ABI: a plain-C program (tests/abi_c_client.c, gcc, no Python/torch in the process)
+    renders through libnerf_mi355.so and agrees with the Python mirror bit for bit."""
+    import os
+    import re
+    import subprocess
+    import nerf_and_dietnerf_amd as N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(N._lib.LIB_PATH)
+    exe = str(tmp_path / "abi_c_client")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_c_client.c"),
+                    "-o", exe, "-L" + libdir, "-lnerf_mi355", "-Wl,-rpath," + libdir, "-lm"], check=True)
+    bc, bf = N.glorot_blob(5), N.glorot_blob(6)
+    c2w = oracle.get_sphere_matrix(1.0, -30.0, 45.0, 0.0).astype(np.float32)
+    wfile = tmp_path / "w.bin"
+    np.concatenate([bc, bf, c2w.ravel()]).astype(np.float32).tofile(str(wfile))
+    res = subprocess.run([exe, str(wfile)], check=True, capture_output=True, text=True, timeout=120)
+    m = re.search(r"checksum ([-\d.e+]+)", res.stdout)
+    assert m, res.stdout + res.stderr
+    ctx = N.Context(near=2.0 / 3.0, far=5.0 / 3.0)
+    ctx.load_weights(0, bc); ctx.load_weights(1, bf)
+    out = ctx.render_image(c2w, 0.6911112, 16, 16, 0, 64, 128, seed=12345, want_depth=True, rgb_only=True)
+    assert abs(float(m.group(1)) - float(out[0].astype(np.float64).sum())) < 1e-6
+    px = re.search(r"pixel255 (\S+) (\S+) (\S+) depth255 (\S+)", res.stdout)
+    got = np.array([float(px.group(i)) for i in range(1, 5)], np.float32)
+    np.testing.assert_array_equal(got[:3], out[0].reshape(-1, 3)[255])
+    np.testing.assert_array_equal(got[3], out[6].reshape(-1)[255])
+    ctx.close()
