@@ -25,6 +25,15 @@ __device__ __forceinline__ f32x4 lds_read4(uint32_t byte_off) {
     return *reinterpret_cast<const f32x4*>(smem + byte_off);
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct Pipe {
     int ck;             // chunk being consumed (monotonic; ring position = ck % kRingChunks)
     int src_next;       // next chunk index of the cyclic weight stream to DMA (0..kStreamChunks-1)
@@ -45,16 +54,27 @@ struct Pipe {
 // Each piece costs ~60 issue cycles, about one 64-cycle MFMA: pieces are dealt out one per MFMA gap
 // (4 in a row after the barrier cost ~170 idle MFMA cycles per chunk, measured).
 __device__ __forceinline__ void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
+    // M0 carries the LDS destination.  It is NOT saved/restored (worth 1 % of the f16x3 kernel): nothing
+    // else in these kernels uses M0, which tools/check_m0.py verifies on the generated ISA at build time.
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %1"
+        :
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
+}
+
+// Piece j of a group of 4 that shares one M0: the 13-bit instruction offset advances the global AND the LDS
+// address alike (measured: tools/microbench/lds_dma_offset.hip), so only the first piece of a group
+// writes M0 and no per-piece address arithmetic is needed.
+template <int OFF, bool SET_M0>
+__device__ __forceinline__ void dma_piece_off(const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    if constexpr (SET_M0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                     : : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(OFF) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
 // Mid-chunk synchronisation point of chunk p.ck:
@@ -117,6 +137,38 @@ __device__ __forceinline__ void pipe_sync_t(Pipe& p, int first_unplaced) {
     for (int j = first_unplaced; j < NPIECE; ++j) pipe_piece_t<CQ>(p, j);
 }
 
+// Offset-form pieces (compile-time piece index J): pieces 4g..4g+3 share one M0 / one source base and
+// differ only in the instruction offset.  FORCE_M0 must be set when the piece is not issued right after
+// piece J-1 of the same chunk (the tail case, where several pieces go out at the sync).
+template <int J, bool FORCE_M0>
+__device__ __forceinline__ void pipe_piece_c(Pipe& p) {
+#if !(defined(NERF_DIAG) && NERF_DIAG == 2)
+    constexpr int G = J >> 2, O = J & 3;
+    dma_piece_off<O * kQuadBytes, (O == 0) || FORCE_M0>(p.cur_src + G * 4 * kQuadBytes, p.voff,
+                                                        p.cur_dst + G * 4 * kQuadBytes);
+#endif
+}
+
+// pipe_sync_t with a compile-time first_unplaced (so its pieces can use the offset form)
+template <int CQ, int RING, int FIRST_UNPLACED>
+__device__ __forceinline__ void pipe_sync_c(Pipe& p) {
+    constexpr int NPIECE = CQ / 4;
+#if defined(NERF_DIAG) && NERF_DIAG == 2
+    asm volatile("" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(NPIECE * (RING - 3)) : "memory");
+#if !(defined(NERF_DIAG) && NERF_DIAG == 1)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+#endif
+    p.cur_src = p.wbase + (size_t)p.src_next * (CQ * kQuadBytes);
+    p.cur_dst = kLdsRing + ((p.ck + RING - 1) & (RING - 1)) * (CQ * kQuadBytes) + p.wave_lds;
+    p.src_next = (p.src_next + 1 == p.n_chunks) ? 0 : p.src_next + 1;
+    pipe_piece_c<0, true>(p);
+    static_for<FIRST_UNPLACED, NPIECE>([&](auto jc) { pipe_piece_c<decltype(jc)::value, true>(p); });
+}
+
 enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
 
 #ifdef NERF_STAMPS   // diagnostic build only: per-phase cycle sums of wave 0 of workgroup 0
@@ -130,14 +182,6 @@ enum { BODY_PE = 0, BODY_HID = 1, BODY_SKIP = 2, BODY_LAST = 3 };
 #define STAMP(var) do { } while (0)
 #endif
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 
 }  // namespace nerf

@@ -151,6 +151,8 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         else { nh[n][e >> 1] = ph; nl[n][e >> 1] = pl; }
     };
 
+    float ycarry = 0.f;
+    (void)ycarry;
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         f32x16& acc = accs[u & 3];
@@ -170,9 +172,14 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 if constexpr (qc == kHCQ / 2) {
                     // pieces 1.. go out at quads +2, +4, ...; those that would fall past the body's end go now
                     constexpr int room = (NQ - 1 - Q) / 2;                 // pieces that still find a quad
-                    pipe_sync_t<kHCQ, kHRing>(p, room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4);
+                    pipe_sync_c<kHCQ, kHRing, (room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4)>(p);
                 }
-                if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) pipe_piece_t<kHCQ>(p, (qc - kHCQ / 2) / 2);
+                if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) {
+                    // was this chunk's sync a tail case (pieces issued out of order)?  then re-establish M0
+                    constexpr int Qs = Q - (qc - kHCQ / 2);
+                    constexpr bool tail = (NQ - 1 - Qs) / 2 + 1 < kHCQ / 4;
+                    pipe_piece_c<(qc - kHCQ / 2) / 2, tail>(p);
+                }
                 // quad Q has landed once at most the kPf-1 younger fragment reads are outstanding
                 lds_wait_frag_asm<(NQ - Q >= kPf ? kPf - 1 : NQ - Q - 1)>(pf[Q % kPf]);
                 araw[t] = pf[Q % kPf];
@@ -198,25 +205,25 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 else { bh_ = dh[n - kHStepsHid]; bl_ = dl[n - kHStepsHid]; }
             }
             const h8 b_hi = __builtin_bit_cast(h8, bh_), b_lo = __builtin_bit_cast(h8, bl_);
-            // ---- which deferred epilogue work rides on this k-step (register pair `er` of tile `et`) ----
-            constexpr bool kPend = (u == 0) && PENDING && n < 8;           // previous layer's tile 7
-            constexpr bool kPrev = (u > 0) && BODY != BODY_PE && n < 8;    // this layer's previous tile
-            constexpr bool kEpi = kPend || kPrev;
+            // Deferred epilogue: within a layer ONE accumulator register of the previous tile per k-step over
+            // all 16 steps (fragment dwords are packed on odd steps); the previous LAYER's tile 7 goes a pair per
+            // step over steps 0..7 because its fragments are read from step 14 on.
+            constexpr bool kPend = (u == 0) && PENDING && n < 8;
+            constexpr bool kPrevS = (u > 0) && BODY != BODY_PE && NSTEP >= 16 && n < 16;
             constexpr int et = kPend ? 7 : (u > 0 ? u - 1 : 0);
-            constexpr int er = 2 * (n < 8 ? n : 0);
-            constexpr bool kXc = BODY == BODY_LAST && kPrev;               // layer 8: fp32 for the rgb head
-            float y0 = 0.f, y1 = 0.f;
-
-            // x*w ~= hi_w*lo_x + lo_w*hi_x + hi_w*hi_x, on top of C-in = bias
+            constexpr bool kXc = BODY == BODY_LAST && kPrevS;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
-            if constexpr (kEpi) y0 = act(prv[er]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
-            if constexpr (kEpi) y1 = act(prv[er + 1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
-            if constexpr (kEpi) {
-                if constexpr (kXc) { xc[et * 16 + er] = y0; xc[et * 16 + er + 1] = y1; }
-                else if constexpr (kPend) store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{});
-                else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, er>{}, y0, y1, std::false_type{});
+            if constexpr (kPend) {
+                constexpr int er = 2 * n;
+                const float y0 = act(prv[er]), y1 = act(prv[er + 1]);
+                store_pair(std::integral_constant<int, 7>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{});
+            } else if constexpr (kPrevS) {
+                const float y = act(prv[n]);
+                if constexpr (kXc) xc[et * 16 + n] = y;
+                else if constexpr ((n & 1) == 0) ycarry = y;
+                else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, std::false_type{});
             }
             if constexpr (u == 0 && PENDING) {
                 // previous layer's tile 6 sits complete in nh/nl[12..13]; its k-steps are long retired
@@ -250,7 +257,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
         sigma_raw = accs[(NU - 1) & 3][0];
     }
-    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_t<kHCQ, kHRing>(p, 1);
+    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1>(p);
     p.ck += 1;
 }
 
