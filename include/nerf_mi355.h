@@ -130,6 +130,13 @@ int nerf_render_image(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int
                       const float* u_coarse, const float* u_fine, uint64_t seed,
                       const nerf_outputs* outs, int mem);
 
+/* ---- status ------------------------------------------------------------------------------ */
+/* Synchronises and returns (then clears) the number of sample rows whose network output was not finite
+ * since the last read.  NERF_PRECISION_F16X3 needs |activations| < 65504 (fp16 range); a non-zero count
+ * there means: switch this model to NERF_PRECISION_FP32.  The reference has no such check (TF propagates
+ * NaN silently). */
+int nerf_ctx_read_nonfinite(nerf_ctx* ctx, int64_t* rows);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* When enabled, every fused PE+MLP kernel launch is bracketed by HIP events on the ctx stream.
  * nerf_ctx_read_timing synchronises, returns the summed kernel time / launch count / MLP rows

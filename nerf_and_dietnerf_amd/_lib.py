@@ -55,6 +55,7 @@ SYMBOLS = [
     ("nerf_render", C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, C.POINTER(NerfOutputs), C.c_int]),
     ("nerf_render_image", C.c_int, [_P, _P, _F, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P, _P, _U64,
                                     C.POINTER(NerfOutputs), C.c_int]),
+    ("nerf_ctx_read_nonfinite", C.c_int, [_P, C.POINTER(_I64)]),
     ("nerf_ctx_enable_timing", C.c_int, [_P, C.c_int]),
     ("nerf_ctx_read_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
 ]

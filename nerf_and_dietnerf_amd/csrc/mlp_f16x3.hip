@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
             f32x4 out;
             out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = sigma_raw;
             *reinterpret_cast<f32x4*>(a.raw + m * 4) = out;
+            // overflow / NaN watch (the f16x3 mode saturates above 65504): count, never hide
+            const float chk = out[0] + out[1] + out[2] + out[3];
+            if (a.nonfinite && !(fabsf(chk) <= 3.0e38f)) atomicAdd(a.nonfinite, 1ull);
         }
         STAMP(t0); acc_t[5] += t0 - t1; acc_t[6] += 1;
     }

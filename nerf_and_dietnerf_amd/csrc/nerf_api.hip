@@ -68,6 +68,7 @@ struct nerf_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     long long timed_rows = 0;
+    unsigned long long* nonfinite = nullptr;   // device counter fed by the MLP kernels
 };
 
 namespace {
@@ -122,6 +123,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
     a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
     a.wconst = f16 ? c->net[which].cst_h : c->net[which].cst;
     a.in_a = in_a; a.in_b = in_b; a.z = z; a.raw = raw; a.M = M; a.S = S; a.mode = mode;
+    a.nonfinite = c->nonfinite;
     a.alpha = c->cfg.leaky_relu_alpha;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -253,6 +255,11 @@ int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out) {
         return fail("hipStreamCreate failed");
     }
     c->stream = c->own_stream;
+    if (hipMalloc((void**)&c->nonfinite, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->nonfinite, 0, sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return fail("hipMalloc of the status counter failed");
+    }
     mlp_fp32_set_attributes();
     mlp_f16x3_set_attributes();
     *out = c;
@@ -274,6 +281,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         if (n.cst_h) (void)hipFree(n.cst_h);
     }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->nonfinite) (void)hipFree(c->nonfinite);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -550,6 +558,17 @@ int nerf_render_image(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32
             return r;
     }
     if (mem == NERF_MEM_HOST) return copy_back_outputs(c, outs, &dev, N, S);
+    return 0;
+}
+
+int nerf_ctx_read_nonfinite(nerf_ctx* c, int64_t* rows) {
+    if (!c || !rows) return fail("NULL argument");
+    ENTER(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    HIP_OK(hipMemcpy(&v, c->nonfinite, sizeof v, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemset(c->nonfinite, 0, sizeof v));
+    *rows = (int64_t)v;
     return 0;
 }
 

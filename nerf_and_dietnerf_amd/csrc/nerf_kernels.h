@@ -60,6 +60,7 @@ struct MlpArgs {
     const float* in_b;      // mode 0: rays_dirs (N,4)   | mode 1: view_dirs (M,3)
     const float* z;         // mode 0: (N,S)             | mode 1: unused
     float* raw;             // (M,4) raw [r,g,b,sigma]
+    unsigned long long* nonfinite;   // device counter: rows whose raw output is not finite (may be null)
     long long M;            // number of samples (rows)
     int S;                  // samples per ray (mode 0)
     int mode;

@@ -151,6 +151,13 @@ class Context:
         _lib.check(self.lib.nerf_ctx_set_stream(self.h, C.c_void_p(cur)))
         self._stream = cur
 
+    def read_nonfinite(self) -> int:
+        """Rows with a non-finite network output since the last call (synchronises).  Non-zero in the
+        f16x3 mode means activations left the fp16 range: use precision="fp32" for this model."""
+        n = C.c_int64()
+        _lib.check(self.lib.nerf_ctx_read_nonfinite(self.h, C.byref(n)))
+        return n.value
+
     def enable_timing(self, on: bool = True) -> None:
         _lib.check(self.lib.nerf_ctx_enable_timing(self.h, int(on)))
 

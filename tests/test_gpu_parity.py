@@ -563,3 +563,24 @@ def test_c_abi_client(tmp_path, oracle):
     np.testing.assert_array_equal(got[:3], out[0].reshape(-1, 3)[255])
     np.testing.assert_array_equal(got[3], out[6].reshape(-1)[255])
     ctx.close()
+
+
+def test_nonfinite_watch(golden_ckpt, golden_vec):
+    """Activations beyond the fp16 range are counted (f16x3) while the fp32 mode stays finite."""
+    import nerf_and_dietnerf_amd as N
+    ctx = N.Context(near=float(golden_ckpt["near"]), far=float(golden_ckpt["far"]), precision="f16x3")
+    blob = golden_ckpt["blob_coarse"].copy()
+    ctx.load_weights(0, blob)
+    o, d, z = golden_vec["rays_orig"], golden_vec["rays_dirs"], golden_vec["z_coarse"]
+    ctx.render_rays(0, o, d, z)
+    assert ctx.read_nonfinite() == 0
+    big = blob.copy()
+    big[33 * 256 + 256: 33 * 256 + 256 + 256 * 256] *= 3e4        # layer-1 kernel: activations ~1e5 > 65504
+    ctx.load_weights(0, big)
+    ctx.render_rays(0, o, d, z)
+    assert ctx.read_nonfinite() > 0
+    assert ctx.read_nonfinite() == 0                                # cleared by the read
+    ctx.set_precision("fp32")
+    out = ctx.render_rays(0, o, d, z)
+    assert ctx.read_nonfinite() == 0 and np.isfinite(out[0]).all()
+    ctx.close()
