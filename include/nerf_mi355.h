@@ -137,6 +137,40 @@ int nerf_render_image(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int
  * NaN silently). */
 int nerf_ctx_read_nonfinite(nerf_ctx* ctx, int64_t* rows);
 
+/* ---- training ---------------------------------------------------
+ * Replaces NeRF.train_step (src/NeRF.py:136-178) under model.compile(optimizer=Adam(lr))
+ * (src/ExecutionRun.py:226-227), fp32 policy:
+ *   z = get_z_values(jitter); coarse render -> MSE; z_from_dist = inverse-CDF(weights_coarse) -- differentiated
+ *   through, as the reference's tape does (no stop_gradient in src/UtilsCV.py:502-539); fine render on the
+ *   Sf new samples only -> MSE; loss = sum; gradients of both networks; Adam; metrics loss/psnr_coarse/psnr_fine.
+ * Weights, gradients and Adam moments are flat blobs in Keras get_weights() order (as nerf_load_weights). */
+typedef struct nerf_train_config {
+    float learning_rate;       /* Adam(optimizer_lr), src/ExecutionRun.py:226 */
+    float beta_1, beta_2;      /* Keras defaults 0.9, 0.999 */
+    float epsilon;             /* Keras default 1e-7 */
+    int32_t sampler_gradient;  /* 1 = reference behaviour; 0 = treat z_from_dist as data (classic NeRF) */
+} nerf_train_config;
+
+/* Starts a trainer on the weights currently loaded (coarse required, fine optional); zero Adam moments. */
+int nerf_train_begin(nerf_ctx* ctx, const nerf_train_config* cfg);
+/* Packs the trained weights for the render path and frees optimizer state and activation buffers. */
+int nerf_train_end(nerf_ctx* ctx);
+int nerf_train_set_learning_rate(nerf_ctx* ctx, float learning_rate);
+/* One NeRF.train_step on N rays: rays_orig/rays_dirs (N,4), target_rgb (N,3); u_coarse (N,Sc) / u_fine (N,Sf)
+ * NULL -> on-device Philox(seed, ray index in the batch).  metrics (host, nullable): loss, psnr_coarse, psnr_fine;
+ * passing it synchronises.  Sf = 0 (or no fine network) trains the coarse network alone (src/NeRF.py:153). */
+int nerf_train_step(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* target_rgb,
+                    int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
+                    float* metrics, int mem);
+/* The two halves of a step, for data-parallel training: gradients (kept in the ctx and optionally copied out
+ * as blobs), then -- after the caller averaged them over ranks -- the Adam update (NULL = use the ctx's own). */
+int nerf_train_gradients(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* target_rgb,
+                         int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine,
+                         uint64_t seed, float* grad_coarse, float* grad_fine, float* metrics, int mem);
+int nerf_train_apply(nerf_ctx* ctx, const float* grad_coarse, const float* grad_fine, int mem);
+/* Current weights of a network as a blob (model.get_weights(), src/UtilsFiles.py:153-164 saves these). */
+int nerf_get_weights(nerf_ctx* ctx, int which, float* blob, size_t n_floats, int mem);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* When enabled, every fused PE+MLP kernel launch is bracketed by HIP events on the ctx stream.
  * nerf_ctx_read_timing synchronises, returns the summed kernel time / launch count / MLP rows

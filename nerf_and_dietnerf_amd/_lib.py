@@ -27,6 +27,11 @@ class NerfConfig(C.Structure):
     ]
 
 
+class NerfTrainConfig(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float),
+                ("epsilon", C.c_float), ("sampler_gradient", C.c_int32)]
+
+
 class NerfOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("rgb", "weights", "cumprod", "alpha", "rgb_samples", "z", "depth")]
@@ -56,6 +61,13 @@ SYMBOLS = [
     ("nerf_render_image", C.c_int, [_P, _P, _F, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P, _P, _U64,
                                     C.POINTER(NerfOutputs), C.c_int]),
     ("nerf_ctx_read_nonfinite", C.c_int, [_P, C.POINTER(_I64)]),
+    ("nerf_train_begin", C.c_int, [_P, C.POINTER(NerfTrainConfig)]),
+    ("nerf_train_end", C.c_int, [_P]),
+    ("nerf_train_set_learning_rate", C.c_int, [_P, _F]),
+    ("nerf_train_step", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, C.c_int]),
+    ("nerf_train_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, _P, _P, C.c_int]),
+    ("nerf_train_apply", C.c_int, [_P, _P, _P, C.c_int]),
+    ("nerf_get_weights", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_ctx_enable_timing", C.c_int, [_P, C.c_int]),
     ("nerf_ctx_read_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
 ]

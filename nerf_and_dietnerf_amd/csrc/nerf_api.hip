@@ -14,13 +14,13 @@
 #include <string>
 #include <vector>
 
-#include "nerf_kernels.h"
+#include "nerf_ctx.h"
 
 using namespace nerf;
 
-namespace {
-
 thread_local std::string g_err;
+
+namespace nerf {
 
 int fail(const char* fmt, ...) {
     char buf[512];
@@ -31,47 +31,6 @@ int fail(const char* fmt, ...) {
     g_err = buf;
     return 1;
 }
-
-#define HIP_OK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e__ = (expr);                                                                  \
-        if (e__ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                                           __FILE__, __LINE__);                                   \
-    } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct NetWeights {
-    float* stream = nullptr;     // kStreamBytes      (fp32 MFMA operand stream)
-    float* cst = nullptr;        // kConstBytes
-    void* stream_h = nullptr;    // kStreamBytesF16   (fp16 hi/lo fragment stream)
-    float* cst_h = nullptr;      // kConstBytes
-    bool loaded = false;
-};
-
-}  // namespace
-
-struct nerf_ctx {
-    nerf_config cfg;
-    int num_cus = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    NetWeights net[2];
-    // scratch arena (grow-only)
-    DevBuf b_orig, b_dirs, b_zc, b_zf, b_raw, b_wc, b_u0, b_u1, b_in0, b_in1, b_in2;
-    DevBuf b_out[7];
-    // timing
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    long long timed_rows = 0;
-    unsigned long long* nonfinite = nullptr;   // device counter fed by the MLP kernels
-};
-
-namespace {
 
 int ensure(nerf_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
@@ -96,7 +55,34 @@ int enter(nerf_ctx* c) {
     HIP_OK(hipSetDevice(c->cfg.device));
     return 0;
 }
-#define ENTER(c) do { if (int r__ = enter(c)) return r__; } while (0)
+
+int upload_packed_weights(nerf_ctx* c, int which, const float* blob) {
+    HIP_OK(hipSetDevice(c->cfg.device));
+    std::vector<float> st(kStreamBytes / 4), cs(kConstFloats);
+    pack_weights_fp32(blob, c->cfg.n_angles, st.data(), cs.data());
+    NetWeights& n = c->net[which];
+    if (!n.stream) HIP_OK(hipMalloc((void**)&n.stream, kStreamBytes));
+    if (!n.cst) HIP_OK(hipMalloc((void**)&n.cst, kConstBytes));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(n.stream, st.data(), kStreamBytes, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(n.cst, cs.data(), kConstBytes, hipMemcpyHostToDevice));
+    // both operand formats are kept resident (2 x 2.1 MB per network) so precision can be switched per call
+    std::vector<uint16_t> sth(kStreamBytesF16 / 2);
+    std::vector<float> csh(kConstFloats);
+    pack_weights_f16x3(blob, c->cfg.n_angles, sth.data(), csh.data());
+    if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16));
+    if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
+    HIP_OK(hipMemcpy(n.stream_h, sth.data(), kStreamBytesF16, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(n.cst_h, csh.data(), kConstBytes, hipMemcpyHostToDevice));
+    const size_t nf = nerf_blob_size(&c->cfg);
+    if (n.host_blob.data() != blob) n.host_blob.assign(blob, blob + nf);
+    n.loaded = true;
+    return 0;
+}
+
+}  // namespace nerf
+
+namespace {
 
 int check_cfg(const nerf_config* cfg) {
     if (!cfg) return fail("nerf_config is NULL");
@@ -118,6 +104,7 @@ int check_cfg(const nerf_config* cfg) {
 int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const float* z, float* raw, long long M,
             int S, int mode) {
     if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
+    if (int r = train_flush_weights(c, which)) return r;   // re-pack the operand streams after optimizer steps
     const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3;
     MlpArgs a;
     a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
@@ -281,6 +268,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         if (n.cst_h) (void)hipFree(n.cst_h);
     }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    train_free(c);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -319,25 +307,8 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* blob, size_t n_floats
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail("which must be 0 (coarse) or 1 (fine)");
     const size_t want = nerf_blob_size(&c->cfg);
     if (n_floats != want) return fail("weight blob has %zu floats, expected %zu", n_floats, want);
-    HIP_OK(hipSetDevice(c->cfg.device));
-    std::vector<float> st(kStreamBytes / 4), cs(kConstFloats);
-    pack_weights_fp32(blob, c->cfg.n_angles, st.data(), cs.data());
-    NetWeights& n = c->net[which];
-    if (!n.stream) HIP_OK(hipMalloc((void**)&n.stream, kStreamBytes));
-    if (!n.cst) HIP_OK(hipMalloc((void**)&n.cst, kConstBytes));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    HIP_OK(hipMemcpy(n.stream, st.data(), kStreamBytes, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(n.cst, cs.data(), kConstBytes, hipMemcpyHostToDevice));
-    // both operand formats are kept resident (2 x 2.1 MB per network) so precision can be switched per call
-    std::vector<uint16_t> sth(kStreamBytesF16 / 2);
-    std::vector<float> csh(kConstFloats);
-    pack_weights_f16x3(blob, c->cfg.n_angles, sth.data(), csh.data());
-    if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16));
-    if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
-    HIP_OK(hipMemcpy(n.stream_h, sth.data(), kStreamBytesF16, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(n.cst_h, csh.data(), kConstBytes, hipMemcpyHostToDevice));
-    n.loaded = true;
-    return 0;
+    if (int r = upload_packed_weights(c, which, blob)) return r;
+    return train_on_load(c, which);      // a running trainer restarts from the new weights
 }
 
 int nerf_get_rays_directions(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32_t W, float* dirs, int mem) {

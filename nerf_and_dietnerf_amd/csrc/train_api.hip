@@ -1,0 +1,483 @@
+// train_api.hip -- C ABI of the training path (include/nerf_mi355.h, "training" section):
+//   NeRF.train_step            src/NeRF.py:136-178   (loss, gradients of both networks, optimizer step, metrics)
+//   Adam(optimizer_lr)         src/ExecutionRun.py:226 (Keras-2.7 defaults beta_1=.9 beta_2=.999 epsilon=1e-7)
+// Orchestration only: every arithmetic step is a HIP kernel of train_kernels.hip / aux_kernels.hip on the
+// context's stream.  Master weights, gradients and Adam moments live on the device as flat blobs in Keras
+// get_weights() order; padded [K x N] / [N x K] copies feed the GEMMs and are rebuilt after every update.
+#include <math.h>
+#include <string.h>
+
+#include "nerf_ctx.h"
+#include "train_kernels.h"
+
+using namespace nerf;
+
+namespace nerf {
+
+struct TLayer {
+    int K_real, N_real, Kp, Np, rowmap;
+    size_t w_off, b_off;           // offsets into the blob
+    float *W, *WT, *bias;          // padded copies (device)
+};
+
+struct TNet {
+    bool present = false;
+    bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
+    float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
+    TLayer L[11];
+};
+
+struct TPass {                      // activations of one pass, kept from forward to backward
+    DevBuf C4, C8, H1, H2, H3, H5, H6, H7, H9, raw, T, w, rgb, z;
+};
+
+struct TrainState {
+    nerf_train_config cfg;
+    long long step = 0;
+    size_t nblob = 0;
+    TNet net[2];
+    TPass pass[2];
+    DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal;
+};
+
+}  // namespace nerf
+
+namespace {
+
+void layer_table(const nerf_config& cfg, TLayer L[11]) {
+    const int kd = 8 * (cfg.n_angles + 1);
+    const int shape[11][5] = {
+        {33, 256, kXyzPad, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
+        {289, 256, kLdC4, 256, 1},  {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
+        {256 + kd, 128, kLdC8, 128, 0}, {128, 3, 128, 32, 0}, {256 + kd, 1, kLdC8, 32, 0}};
+    size_t off = 0;
+    for (int l = 0; l < 11; ++l) {
+        L[l].K_real = shape[l][0]; L[l].N_real = shape[l][1]; L[l].Kp = shape[l][2]; L[l].Np = shape[l][3];
+        L[l].rowmap = shape[l][4];
+        L[l].w_off = off; off += (size_t)L[l].K_real * L[l].N_real;
+        L[l].b_off = off; off += L[l].N_real;
+        L[l].W = L[l].WT = L[l].bias = nullptr;
+    }
+}
+
+void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+int relayout_net(nerf_ctx* c, TNet& n) {
+    for (int l = 0; l < 11; ++l) {
+        const TLayer& L = n.L[l];
+        RelayoutArgs a;
+        a.w = n.blob + L.w_off; a.b = n.blob + L.b_off;
+        a.K_real = L.K_real; a.N_real = L.N_real; a.Kp = L.Kp; a.Np = L.Np; a.rowmap = L.rowmap;
+        a.W = L.W; a.WT = L.WT; a.bias = L.bias;
+        launch_relayout(a, c->stream);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int init_net(nerf_ctx* c, TrainState* t, int which) {
+    TNet& n = t->net[which];
+    layer_table(c->cfg, n.L);
+    const size_t nb = t->nblob * sizeof(float);
+    HIP_OK(hipMalloc((void**)&n.blob, nb));
+    HIP_OK(hipMalloc((void**)&n.grad, nb));
+    HIP_OK(hipMalloc((void**)&n.m, nb));
+    HIP_OK(hipMalloc((void**)&n.v, nb));
+    HIP_OK(hipMemsetAsync(n.m, 0, nb, c->stream));
+    HIP_OK(hipMemsetAsync(n.v, 0, nb, c->stream));
+    HIP_OK(hipMemsetAsync(n.grad, 0, nb, c->stream));
+    size_t mats = 0;
+    for (int l = 0; l < 11; ++l) mats += 2 * (size_t)n.L[l].Kp * n.L[l].Np + n.L[l].Np;
+    HIP_OK(hipMalloc((void**)&n.mats, mats * sizeof(float)));
+    float* p = n.mats;
+    for (int l = 0; l < 11; ++l) {
+        TLayer& L = n.L[l];
+        L.W = p; p += (size_t)L.Kp * L.Np;
+        L.WT = p; p += (size_t)L.Kp * L.Np;
+        L.bias = p; p += L.Np;
+    }
+    HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), nb, hipMemcpyHostToDevice, c->stream));
+    n.present = true;
+    n.render_dirty = false;
+    return relayout_net(c, n);
+}
+
+// ---- one pass: forward ---------------------------------------------------------------------------
+struct PassDims { long long N; int S; long long M, Mp; };
+
+int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
+    const size_t f = sizeof(float);
+    int r = 0;
+    r |= ensure(c, p.C4, d.Mp * kLdC4 * f);
+    r |= ensure(c, p.C8, d.Mp * kLdC8 * f);
+    DevBuf* hs[] = {&p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7};
+    for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * 256 * f);
+    r |= ensure(c, p.H9, d.Mp * 128 * f);
+    r |= ensure(c, p.raw, d.Mp * 4 * f);
+    r |= ensure(c, p.T, d.M * f);
+    r |= ensure(c, p.w, d.M * f);
+    r |= ensure(c, p.rgb, d.N * 3 * f);
+    r |= ensure(c, p.z, d.M * f);
+    return r;
+}
+
+void fwd_layer(nerf_ctx* c, const TLayer& L, const float* A, int lda, float* Out, int ldo, long long Mp,
+               bool linear_head = false, int n_valid = -1) {
+    GemmAbt g{};
+    g.A = A; g.lda = lda; g.Bt = L.WT; g.ldb = L.Kp; g.Out = Out; g.ldo = ldo;
+    g.M = Mp; g.N = L.Np; g.K = L.Kp; g.bias = L.bias; g.alpha = c->cfg.leaky_relu_alpha;
+    g.n_valid = n_valid < 0 ? L.Np : n_valid;
+    launch_gemm_abt(linear_head ? EPI_FWD_LINEAR : EPI_FWD_LEAKY, linear_head, g, c->stream);
+}
+
+int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const float* o, const float* dirs) {
+    TNet& n = t->net[which];
+    TPass& p = t->pass[which];
+    float *C4 = (float*)p.C4.p, *C8 = (float*)p.C8.p, *raw = (float*)p.raw.p, *z = (float*)p.z.p;
+    float *H1 = (float*)p.H1.p, *H2 = (float*)p.H2.p, *H3 = (float*)p.H3.p, *H5 = (float*)p.H5.p,
+          *H6 = (float*)p.H6.p, *H7 = (float*)p.H7.p, *H9 = (float*)p.H9.p;
+    launch_train_encode(o, dirs, z, d.N, d.S, d.Mp, c->cfg.n_angles, C4, C8, c->stream);
+    fwd_layer(c, n.L[0], C4 + 256, kLdC4, H1, 256, d.Mp);
+    fwd_layer(c, n.L[1], H1, 256, H2, 256, d.Mp);
+    fwd_layer(c, n.L[2], H2, 256, H3, 256, d.Mp);
+    fwd_layer(c, n.L[3], H3, 256, C4, kLdC4, d.Mp);          // h4 lands next to xyz_enc: the skip concat
+    fwd_layer(c, n.L[4], C4, kLdC4, H5, 256, d.Mp);
+    fwd_layer(c, n.L[5], H5, 256, H6, 256, d.Mp);
+    fwd_layer(c, n.L[6], H6, 256, H7, 256, d.Mp);
+    fwd_layer(c, n.L[7], H7, 256, C8, kLdC8, d.Mp);          // h8 lands next to dir_enc
+    fwd_layer(c, n.L[8], C8, kLdC8, H9, 128, d.Mp);
+    fwd_layer(c, n.L[9], H9, 128, raw, 4, d.Mp, true, 3);    // rgb head   -> raw[:, 0:3]
+    fwd_layer(c, n.L[10], C8, kLdC8, raw + 3, 4, d.Mp, true, 1);   // sigma head -> raw[:, 3]
+    launch_composite(raw, z, d.N, d.S, (float*)p.rgb.p, (float*)p.w.p, (float*)p.T.p, nullptr, nullptr, nullptr,
+                     c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- one pass: backward --------------------------------------------------------------------------
+void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
+           int n_src_off, long long Mp) {
+    const TLayer& L = n.L[l];
+    GemmAtb g{};
+    g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
+    g.partial = (float*)t->partial.p; g.Kp = L.Kp; g.Nw = Ncols; g.M = Mp;
+    long long rps = (Mp + kTrainSplits - 1) / kTrainSplits;
+    rps = (rps + 15) / 16 * 16;
+    g.rows_per_split = (int)rps;
+    launch_gemm_atb(g, c->stream);
+    ReduceArgs r{};
+    r.partial = g.partial; r.Kp = L.Kp; r.Nw = Ncols; r.splits = (int)((Mp + rps - 1) / rps);
+    r.grad_w = n.grad + L.w_off; r.grad_b = n.grad + L.b_off;
+    r.K_real = L.K_real; r.N_real = L.N_real; r.n_src_off = n_src_off; r.rowmap = L.rowmap;
+    launch_reduce_grad(r, c->stream);
+}
+
+void dgrad(nerf_ctx* c, const float* G, int ldg, int Kg, const float* Wrows, int ldb, int Nout, const float* H, int ldh,
+           float* Out, int ldo, long long Mp, const float* r1a = nullptr, const float* r1b = nullptr) {
+    GemmAbt g{};
+    g.A = G; g.lda = ldg; g.Bt = Wrows; g.ldb = ldb; g.Out = Out; g.ldo = ldo;
+    g.M = Mp; g.N = Nout; g.K = Kg; g.H = H; g.ldh = ldh; g.r1a = r1a; g.r1a_ld = 4; g.r1b = r1b;
+    g.n_valid = Nout; g.alpha = c->cfg.leaky_relu_alpha;
+    launch_gemm_abt(EPI_BWD_MASK, false, g, c->stream);
+}
+
+void dgrad_xyz(nerf_ctx* c, const float* G, const float* Wrows, float* dA0, long long Mp, bool accumulate) {
+    GemmAbt g{};
+    g.A = G; g.lda = 256; g.Bt = Wrows; g.ldb = 256; g.Out = dA0; g.ldo = kXyzPad;
+    g.M = Mp; g.N = kXyzPad; g.K = 256; g.n_valid = kXyzPad; g.accumulate = accumulate ? 1 : 0;
+    launch_gemm_abt(EPI_BWD_PLAIN, true, g, c->stream);
+}
+
+// Graw (Mp x 4, padding rows zero) must be filled; writes n.grad; with d_z != NULL adds dL/dz through the
+// sample positions (d_z must already hold the compositing part).
+int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const float* o, const float* dirs,
+                  float* d_z) {
+    TNet& n = t->net[which];
+    TPass& p = t->pass[which];
+    const long long Mp = d.Mp;
+    float *C4 = (float*)p.C4.p, *C8 = (float*)p.C8.p;
+    float *H1 = (float*)p.H1.p, *H2 = (float*)p.H2.p, *H3 = (float*)p.H3.p, *H5 = (float*)p.H5.p,
+          *H6 = (float*)p.H6.p, *H7 = (float*)p.H7.p, *H9 = (float*)p.H9.p;
+    float *Ga = (float*)t->Ga.p, *Gb = (float*)t->Gb.p, *G9 = (float*)t->G9.p, *Graw = (float*)t->Graw.p,
+          *dA0 = (float*)t->dA0.p;
+    const bool dx = d_z != nullptr;
+    wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
+    wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
+    launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
+    wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp);
+    // dL/dh8 = G9 . W8[hidden rows]^T + Graw[:,3] * W10[hidden rows]   (WT10 row 0 = the sigma head's column)
+    dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[10].WT);
+    wgrad(c, t, n, 7, H7, 256, Ga, 256, 256, 0, Mp);
+    dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp);
+    wgrad(c, t, n, 6, H6, 256, Gb, 256, 256, 0, Mp);
+    dgrad(c, Gb, 256, 256, n.L[6].W, 256, 256, H6, 256, Ga, 256, Mp);
+    wgrad(c, t, n, 5, H5, 256, Ga, 256, 256, 0, Mp);
+    dgrad(c, Ga, 256, 256, n.L[5].W, 256, 256, H5, 256, Gb, 256, Mp);
+    wgrad(c, t, n, 4, C4, kLdC4, Gb, 256, 256, 0, Mp);
+    dgrad(c, Gb, 256, 256, n.L[4].W, 256, 256, C4, kLdC4, Ga, 256, Mp);
+    if (dx) dgrad_xyz(c, Gb, n.L[4].W + (size_t)256 * 256, dA0, Mp, false);     // skip connection's xyz rows
+    wgrad(c, t, n, 3, H3, 256, Ga, 256, 256, 0, Mp);
+    dgrad(c, Ga, 256, 256, n.L[3].W, 256, 256, H3, 256, Gb, 256, Mp);
+    wgrad(c, t, n, 2, H2, 256, Gb, 256, 256, 0, Mp);
+    dgrad(c, Gb, 256, 256, n.L[2].W, 256, 256, H2, 256, Ga, 256, Mp);
+    wgrad(c, t, n, 1, H1, 256, Ga, 256, 256, 0, Mp);
+    dgrad(c, Ga, 256, 256, n.L[1].W, 256, 256, H1, 256, Gb, 256, Mp);
+    wgrad(c, t, n, 0, C4 + 256, kLdC4, Gb, 256, 256, 0, Mp);
+    if (dx) {
+        dgrad_xyz(c, Gb, n.L[0].W, dA0, Mp, true);
+        launch_pe_bwd(dA0, o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int stage_in(nerf_ctx* c, DevBuf& b, const float* src, size_t bytes, int mem, const float** out) {
+    if (!src) { *out = nullptr; return 0; }
+    if (mem == NERF_MEM_DEVICE) { *out = src; return 0; }
+    if (int r = h2d(c, b, src, bytes)) return r;
+    *out = (const float*)b.p;
+    return 0;
+}
+
+int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const float* target, int64_t N, int Sc,
+                   int Sf, const float* u_c, const float* u_f, uint64_t seed, int mem) {
+    TrainState* t = c->train;
+    if (!t) return fail("nerf_train_begin has not been called");
+    if (!rays_o || !rays_d || !target) return fail("NULL argument");
+    if (N <= 0) return fail("need at least one ray (got %lld)", (long long)N);
+    if (Sc < 1 || Sc > 1024) return fail("bad coarse sample count %d", Sc);
+    const bool fine = Sf > 0 && t->net[1].present;
+    if (fine && Sc < 2) return fail("hierarchical sampling needs at least 2 coarse samples (got %d)", Sc);
+    if (fine && Sf > 256) return fail("training supports at most 256 fine samples per ray (got %d)", Sf);
+    const size_t f = sizeof(float);
+    const float *o, *d, *tg, *uc, *uf;
+    if (int r = stage_in(c, t->o, rays_o, N * 4 * f, mem, &o)) return r;
+    if (int r = stage_in(c, t->d, rays_d, N * 4 * f, mem, &d)) return r;
+    if (int r = stage_in(c, t->tgt, target, N * 3 * f, mem, &tg)) return r;
+    if (int r = stage_in(c, t->u_c, u_c, (size_t)N * Sc * f, mem, &uc)) return r;
+    if (int r = stage_in(c, t->u_f, fine ? u_f : nullptr, (size_t)N * (fine ? Sf : 0) * f, mem, &uf)) return r;
+
+    PassDims dc{N, Sc, N * Sc, (N * Sc + 127) / 128 * 128};
+    PassDims df{N, Sf, N * (long long)Sf, (N * (long long)Sf + 127) / 128 * 128};
+    const long long Mmax = fine && df.Mp > dc.Mp ? df.Mp : dc.Mp;
+    int r = ensure_pass(c, t->pass[0], dc);
+    if (fine) r |= ensure_pass(c, t->pass[1], df);
+    r |= ensure(c, t->Ga, Mmax * 256 * f);
+    r |= ensure(c, t->Gb, Mmax * 256 * f);
+    r |= ensure(c, t->G9, Mmax * 128 * f);
+    r |= ensure(c, t->Graw, Mmax * 4 * f);
+    r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
+    r |= ensure(c, t->partial, (size_t)kTrainSplits * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->d_rgb, N * 3 * f);
+    r |= ensure(c, t->d_wext, dc.M * f);
+    r |= ensure(c, t->d_zf, (fine ? df.M : 1) * f);
+    r |= ensure(c, t->scal, 4 * f);
+    if (r) return r;
+    float* scal = (float*)t->scal.p;
+    float* Graw = (float*)t->Graw.p;
+    float* d_rgb = (float*)t->d_rgb.p;
+
+    // coarse forward (src/NeRF.py:146-151)
+    TPass& pc = t->pass[0];
+    launch_z_values(c->cfg.near_boundary, c->cfg.far_boundary, N, Sc, uc, seed, 0, (float*)pc.z.p, c->stream);
+    if (int q = forward_pass(c, t, 0, dc, o, d)) return q;
+    const bool through_sampler = fine && t->cfg.sampler_gradient != 0;
+    if (fine) {
+        // fine forward on the Sf new samples only (src/NeRF.py:155-157)
+        TPass& pf = t->pass[1];
+        launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, (float*)pf.z.p, nullptr,
+                          c->stream);
+        if (int q = forward_pass(c, t, 1, df, o, d)) return q;
+        launch_mse((const float*)pf.rgb.p, tg, N, d_rgb, scal + 1, c->stream);
+        HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
+        float* d_zf = through_sampler ? (float*)t->d_zf.p : nullptr;
+        launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sf, d_rgb, nullptr,
+                             Graw, d_zf, c->stream);
+        if (int q = backward_pass(c, t, 1, df, o, d, d_zf)) return q;
+        if (through_sampler)
+            launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, d_zf,
+                                  (float*)t->d_wext.p, c->stream);
+    }
+    launch_mse((const float*)pc.rgb.p, tg, N, d_rgb, scal + 0, c->stream);
+    HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
+    launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, d_rgb,
+                         through_sampler ? (const float*)t->d_wext.p : nullptr, Graw, nullptr, c->stream);
+    if (int q = backward_pass(c, t, 0, dc, o, d, nullptr)) return q;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int read_metrics(nerf_ctx* c, bool fine, float* metrics) {
+    if (!metrics) return 0;
+    float h[2] = {0.f, 0.f};
+    HIP_OK(hipMemcpyAsync(h, c->train->scal.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    metrics[0] = fine ? h[0] + h[1] : h[0];                            // src/NeRF.py:151,157
+    metrics[1] = (float)(-10.0 * log10((double)h[0]));                  // get_psnr, UtilsNeuralRadianceField.py:123-132
+    metrics[2] = fine ? (float)(-10.0 * log10((double)h[1])) : 0.f;
+    return 0;
+}
+
+int apply_impl(nerf_ctx* c) {
+    TrainState* t = c->train;
+    t->step += 1;
+    const double b1 = t->cfg.beta_1, b2 = t->cfg.beta_2;
+    const double lr_t = (double)t->cfg.learning_rate * sqrt(1.0 - pow(b2, (double)t->step)) / (1.0 - pow(b1, (double)t->step));
+    for (int w = 0; w < 2; ++w) {
+        TNet& n = t->net[w];
+        if (!n.present) continue;
+        launch_adam(n.blob, n.m, n.v, n.grad, t->nblob, (float)lr_t, t->cfg.beta_1, t->cfg.beta_2, t->cfg.epsilon,
+                    c->stream);
+        if (int r = relayout_net(c, n)) return r;
+        n.render_dirty = true;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+namespace nerf {
+
+void train_free(nerf_ctx* c) {
+    TrainState* t = c->train;
+    if (!t) return;
+    for (auto& n : t->net) {
+        if (n.blob) (void)hipFree(n.blob);
+        if (n.grad) (void)hipFree(n.grad);
+        if (n.m) (void)hipFree(n.m);
+        if (n.v) (void)hipFree(n.v);
+        if (n.mats) (void)hipFree(n.mats);
+    }
+    for (auto& p : t->pass) {
+        DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H9, &p.raw, &p.T, &p.w, &p.rgb, &p.z};
+        for (DevBuf* b : bs) free_buf(*b);
+    }
+    DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal};
+    for (DevBuf* b : bs) free_buf(*b);
+    delete t;
+    c->train = nullptr;
+}
+
+int train_on_load(nerf_ctx* c, int which) {
+    TrainState* t = c->train;
+    if (!t) return 0;
+    TNet& n = t->net[which];
+    if (!n.present) return init_net(c, t, which);
+    HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), t->nblob * sizeof(float), hipMemcpyHostToDevice,
+                          c->stream));
+    n.render_dirty = false;
+    return relayout_net(c, n);
+}
+
+int train_flush_weights(nerf_ctx* c, int which) {
+    TrainState* t = c->train;
+    if (!t || !t->net[which].present || !t->net[which].render_dirty) return 0;
+    NetWeights& nw = c->net[which];
+    HIP_OK(hipMemcpyAsync(nw.host_blob.data(), t->net[which].blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost,
+                          c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    t->net[which].render_dirty = false;
+    return upload_packed_weights(c, which, nw.host_blob.data());
+}
+
+}  // namespace nerf
+
+extern "C" {
+
+int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
+    ENTER(c);
+    if (!cfg) return fail("nerf_train_config is NULL");
+    if (!(cfg->learning_rate > 0.f)) return fail("learning_rate must be positive");
+    if (!c->net[0].loaded) return fail("load the coarse network's weights before nerf_train_begin");
+    if (c->train) train_free(c);
+    TrainState* t = new TrainState();
+    t->cfg = *cfg;
+    t->nblob = nerf_blob_size(&c->cfg);
+    c->train = t;
+    for (int w = 0; w < 2; ++w)
+        if (c->net[w].loaded)
+            if (int r = init_net(c, t, w)) { train_free(c); return r; }
+    return 0;
+}
+
+int nerf_train_end(nerf_ctx* c) {
+    ENTER(c);
+    for (int w = 0; w < 2; ++w)
+        if (int r = train_flush_weights(c, w)) return r;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    train_free(c);
+    return 0;
+}
+
+int nerf_train_set_learning_rate(nerf_ctx* c, float lr) {
+    if (!c || !c->train) return fail("nerf_train_begin has not been called");
+    if (!(lr > 0.f)) return fail("learning_rate must be positive");
+    c->train->cfg.learning_rate = lr;
+    return 0;
+}
+
+int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_dirs, const float* target_rgb, int64_t N,
+                         int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
+                         float* grad_coarse, float* grad_fine, float* metrics, int mem) {
+    ENTER(c);
+    if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
+    TrainState* t = c->train;
+    const bool fine = Sf > 0 && t->net[1].present;
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
+    if (grad_fine) {
+        if (!fine) return fail("grad_fine requested but no fine pass ran (Sf = %d)", Sf);
+        HIP_OK(hipMemcpyAsync(grad_fine, t->net[1].grad, t->nblob * sizeof(float), kind, c->stream));
+    }
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return read_metrics(c, fine, metrics);
+}
+
+int nerf_train_apply(nerf_ctx* c, const float* grad_coarse, const float* grad_fine, int mem) {
+    ENTER(c);
+    TrainState* t = c->train;
+    if (!t) return fail("nerf_train_begin has not been called");
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (grad_coarse) HIP_OK(hipMemcpyAsync(t->net[0].grad, grad_coarse, t->nblob * sizeof(float), kind, c->stream));
+    if (grad_fine) {
+        if (!t->net[1].present) return fail("grad_fine given but no fine network is loaded");
+        HIP_OK(hipMemcpyAsync(t->net[1].grad, grad_fine, t->nblob * sizeof(float), kind, c->stream));
+    }
+    if (mem == NERF_MEM_HOST && (grad_coarse || grad_fine)) HIP_OK(hipStreamSynchronize(c->stream));
+    return apply_impl(c);
+}
+
+int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs, const float* target_rgb, int64_t N,
+                    int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed, float* metrics,
+                    int mem) {
+    ENTER(c);
+    if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
+    const bool fine = Sf > 0 && c->train->net[1].present;
+    if (!fine && c->train->net[1].present)   // a skipped fine pass must not move the fine network
+        HIP_OK(hipMemsetAsync(c->train->net[1].grad, 0, c->train->nblob * sizeof(float), c->stream));
+    if (int r = apply_impl(c)) return r;
+    return read_metrics(c, fine, metrics);
+}
+
+int nerf_get_weights(nerf_ctx* c, int which, float* blob, size_t n_floats, int mem) {
+    ENTER(c);
+    if (!blob) return fail("blob is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail("which must be 0 (coarse) or 1 (fine)");
+    if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
+    const size_t want = nerf_blob_size(&c->cfg);
+    if (n_floats != want) return fail("weight blob has %zu floats, expected %zu", n_floats, want);
+    TrainState* t = c->train;
+    if (t && t->net[which].present) {
+        const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        HIP_OK(hipMemcpyAsync(blob, t->net[which].blob, want * sizeof(float), kind, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
+    HIP_OK(hipMemcpy(blob, c->net[which].host_blob.data(), want * sizeof(float), kind));
+    return 0;
+}
+
+}  // extern "C"

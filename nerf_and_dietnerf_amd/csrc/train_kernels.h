@@ -1,0 +1,75 @@
+// train_kernels.h -- internal declarations of the training path (NeRF.train_step, src/NeRF.py:136-178):
+// layer-wise fp32 MFMA GEMMs over activations kept in HBM + the per-ray backward kernels.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nerf {
+
+// padded training layout of the activations (floats per row)
+constexpr int kLdC4 = 320;    // [h4 (256) | xyz_enc (33) | 0-pad to 64]   input of layer 4; cols 256.. = input of layer 0
+constexpr int kLdC8 = 288;    // [h8 (256) | dir_enc (24 or 16) | 0-pad to 32]   input of layers 8 and 10
+constexpr int kXyzPad = 64;
+constexpr int kDirPad = 32;
+constexpr int kTrainSplits = 128;   // row slabs of the weight-gradient reduction
+
+enum { EPI_FWD_LEAKY = 0, EPI_FWD_LINEAR = 1, EPI_BWD_MASK = 2, EPI_BWD_PLAIN = 3 };
+
+// Out[M x N] = epi( A[M x K] . Bt[N x K]^T )      (both operands K-contiguous)
+struct GemmAbt {
+    const float* A; int lda;
+    const float* Bt; int ldb;
+    float* Out; int ldo;
+    long long M;                // multiple of 128
+    int N, K;                   // N multiple of the column tile (128 wide / 32 narrow), K multiple of 16
+    const float* bias;          // FWD_*: [N]
+    const float* H; int ldh;    // BWD_MASK: stored activation of the layer whose pre-activation gradient is produced
+    const float* r1a; int r1a_ld;   // BWD_MASK optional rank-1 term  r1a[m*r1a_ld] * r1b[n]
+    const float* r1b;
+    int n_valid;                // columns actually stored
+    int accumulate;             // BWD_PLAIN: Out += result
+    float alpha;
+};
+void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s);
+
+// partial[split][k][n] = sum over the split's rows of A[m][k] * G[m][n]; row Kp of every split = column sums of G
+struct GemmAtb {
+    const float* A; int lda; int K;     // K = columns of A used (multiple of 4)
+    const float* G; int ldg; int N;     // N = columns of G used (multiple of 4)
+    float* partial; int Kp; int Nw;     // partial: [splits][Kp + 1][Nw]
+    long long M; int rows_per_split;    // multiple of 16
+};
+void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
+
+// grad[blob layout] = sum over splits of partial (deterministic order)
+struct ReduceArgs {
+    const float* partial; int Kp; int Nw; int splits;
+    float* grad_w; float* grad_b;       // destinations inside the gradient blob
+    int K_real, N_real; int n_src_off;  // gradient column n comes from partial column n_src_off + n
+    int rowmap;                         // 0: identity; 1: layer 4 (blob rows [xyz(33); hidden(256)] <- training rows [hidden; xyz])
+};
+void launch_reduce_grad(const ReduceArgs& a, hipStream_t s);
+
+// blob (Keras order) -> padded training matrices W [Kp x Np], WT [Np x Kp], bias [Np]
+struct RelayoutArgs {
+    const float* w; const float* b; int K_real, N_real, Kp, Np, rowmap;
+    float* W; float* WT; float* bias;
+};
+void launch_relayout(const RelayoutArgs& a, hipStream_t s);
+
+void launch_train_encode(const float* o, const float* d, const float* z, long long N, int S, long long Mp,
+                         int n_angles, float* C4, float* C8, hipStream_t s);
+void launch_mse(const float* rgb, const float* target, long long N, float* d_rgb, float* mse_out, hipStream_t s);
+void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
+                          const float* d_w_ext, float* Graw, float* d_z, hipStream_t s);
+void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,
+                     long long M, float alpha, float* G9, hipStream_t s);
+void launch_pe_bwd(const float* dA0, const float* o, const float* d, const float* z, long long N, int S, float* d_z,
+                   hipStream_t s);
+void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
+                           uint64_t seed, long long ray_base, const float* d_zf, float* d_w, hipStream_t s);
+size_t sample_pdf_bwd_lds_bytes(int S, int Sf);
+void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2,
+                 float eps, hipStream_t s);
+
+}  // namespace nerf

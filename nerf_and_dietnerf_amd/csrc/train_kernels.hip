@@ -1,0 +1,673 @@
+// train_kernels.hip -- HIP kernels of the training path (NeRF.train_step, src/NeRF.py:136-178) for gfx950.
+//
+// The render path fuses the whole MLP into one kernel and never writes an activation; a training step needs
+// every layer's activation again in the backward pass, so here the network runs layer by layer over
+// activations resident in HBM (9 KB per sample row; 7 GB for a 4096-ray batch -- 2.5 % of the 288 GB):
+//
+//   gemm_abt   Out = epi(A . Bt^T)        forward layers (bias + LeakyReLU fused) and the data gradients
+//                                         (LeakyReLU' mask and the sigma head's rank-1 term fused)
+//   gemm_atb   dW  = A^T . G              weight gradients: the reduction runs over ~10^6 sample rows, so it is
+//                                         split into row slabs (partials in HBM) and summed in a fixed order;
+//                                         the bias gradient (column sums of G) rides in the same kernel
+// both on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation), 128x128 output tile per workgroup,
+// 4 waves x (64x64), k-step 16 through double-buffered LDS.
+//
+// Per-ray backward kernels: compositing (division-free reverse scan), positional encoding, inverse-CDF sampler
+// (the reference has no stop_gradient there: src/UtilsCV.py:512-537), MSE, Adam.
+#include "train_kernels.h"
+#include "nerf_device.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// gemm_abt
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsLd = 20;   // floats per staged row of 16 (80 B: keeps float4 alignment, spreads banks)
+
+template <int WTM, int WTN, int WVM, int WVN, int EPI>
+__global__ __launch_bounds__(256) void gemm_abt_kernel(const GemmAbt g) {
+    constexpr int TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
+    static_assert(WVM * WVN == 4 && TM == 128, "4 waves, 128 rows per workgroup");
+    __shared__ __attribute__((aligned(16))) float As[2][TM * kLdsLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TN * kLdsLd];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int li = lane & 31, lh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    constexpr int A_F4 = TM * 4 / 256;
+    constexpr int B_F4 = (TN * 4 + 255) / 256;
+    float4 ra[A_F4], rb[B_F4];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+            ra[i] = *reinterpret_cast<const float4*>(g.A + (m0 + row) * g.lda + k0 + 4 * kq);
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+            if (idx < TN * 4) rb[i] = *reinterpret_cast<const float4*>(g.Bt + (size_t)(n0 + row) * g.ldb + k0 + 4 * kq);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+            *reinterpret_cast<float4*>(&As[buf][row * kLdsLd + 4 * kq]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+            if (idx < TN * 4) *reinterpret_cast<float4*>(&Bs[buf][row * kLdsLd + 4 * kq]) = rb[i];
+        }
+    };
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int a = 0; a < WTM; ++a)
+#pragma unroll
+        for (int b = 0; b < WTN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        const int buf = (k0 >> 4) & 1;
+        const bool more = k0 + 16 < g.K;
+        if (more) gload(k0 + 16);
+        // lane (li, lh) holds k = 8*lh + j for MFMA step j: two float4 per operand tile
+        float av[WTM][8], bv[WTN][8];
+#pragma unroll
+        for (int a = 0; a < WTM; ++a) {
+            const float* p = &As[buf][((wm * WTM + a) * 32 + li) * kLdsLd + 8 * lh];
+            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+            av[a][0] = x.x; av[a][1] = x.y; av[a][2] = x.z; av[a][3] = x.w;
+            av[a][4] = y.x; av[a][5] = y.y; av[a][6] = y.z; av[a][7] = y.w;
+        }
+#pragma unroll
+        for (int b = 0; b < WTN; ++b) {
+            const float* p = &Bs[buf][((wn * WTN + b) * 32 + li) * kLdsLd + 8 * lh];
+            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+            bv[b][0] = x.x; bv[b][1] = x.y; bv[b][2] = x.z; bv[b][3] = x.w;
+            bv[b][4] = y.x; bv[b][5] = y.y; bv[b][6] = y.z; bv[b][7] = y.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int a = 0; a < WTM; ++a)
+#pragma unroll
+                for (int b = 0; b < WTN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < WTM; ++a)
+#pragma unroll
+        for (int b = 0; b < WTN; ++b) {
+            const int n = n0 + (wn * WTN + b) * 32 + li;
+            float bias = 0.f, r1b = 0.f;
+            if (EPI == EPI_FWD_LEAKY || EPI == EPI_FWD_LINEAR) bias = g.bias[n];
+            if (EPI == EPI_BWD_MASK && g.r1a) r1b = g.r1b[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * WTM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[a][b][r];
+                if (EPI == EPI_FWD_LEAKY) {
+                    v += bias;
+                    v = v > 0.f ? v : g.alpha * v;
+                } else if (EPI == EPI_FWD_LINEAR) {
+                    v += bias;
+                } else if (EPI == EPI_BWD_MASK) {
+                    if (g.r1a) v = fmaf(g.r1a[m * g.r1a_ld], r1b, v);
+                    v = g.H[m * g.ldh + n] > 0.f ? v : g.alpha * v;
+                } else {
+                    if (g.accumulate) v += g.Out[m * g.ldo + n];
+                }
+                if (n < g.n_valid) g.Out[m * g.ldo + n] = v;
+            }
+        }
+}
+
+template <int EPI>
+static void launch_abt_epi(bool narrow, const GemmAbt& g, hipStream_t s) {
+    if (narrow)
+        hipLaunchKernelGGL((gemm_abt_kernel<1, 1, 4, 1, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 32)),
+                           dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_abt_kernel<2, 2, 2, 2, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 128)),
+                           dim3(256), 0, s, g);
+}
+
+void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s) {
+    if (g.M <= 0) return;
+    switch (epi) {
+        case EPI_FWD_LEAKY: launch_abt_epi<EPI_FWD_LEAKY>(narrow, g, s); break;
+        case EPI_FWD_LINEAR: launch_abt_epi<EPI_FWD_LINEAR>(narrow, g, s); break;
+        case EPI_BWD_MASK: launch_abt_epi<EPI_BWD_MASK>(narrow, g, s); break;
+        default: launch_abt_epi<EPI_BWD_PLAIN>(narrow, g, s); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_atb: 128 (k of A) x 128 (n of G) partial tile per workgroup over one slab of rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAtbLd = 132;   // staged row of 128 floats + 4: lane halves (8 rows apart) fall on opposite banks
+
+__global__ __launch_bounds__(256) void gemm_atb_kernel(const GemmAtb g) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * kAtbLd];
+    __shared__ __attribute__((aligned(16))) float Gs[2][16 * kAtbLd];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kb = blockIdx.x * 128, nb = blockIdx.y * 128, split = blockIdx.z;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    float4 ra[2], rg[2];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto gload = [&](long long mrow) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + 256 * i, row = idx >> 5, c4 = idx & 31;
+            const int ka = kb + 4 * c4, na = nb + 4 * c4;
+            ra[i] = ka < g.K ? *reinterpret_cast<const float4*>(g.A + (mrow + row) * g.lda + ka) : zero4;
+            rg[i] = na < g.N ? *reinterpret_cast<const float4*>(g.G + (mrow + row) * g.ldg + na) : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = t + 256 * i, row = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4*>(&As[buf][row * kAtbLd + 4 * c4]) = ra[i];
+            *reinterpret_cast<float4*>(&Gs[buf][row * kAtbLd + 4 * c4]) = rg[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float colsum = 0.f;
+    const bool do_colsum = blockIdx.x == 0 && t < 128;
+
+    if (ms < me) {
+        gload(ms);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long long mrow = ms; mrow < me; mrow += 16) {
+        const bool more = mrow + 16 < me;
+        if (more) gload(mrow + 16);
+        // MFMA: D[i][j] += sum_kk A[i][kk] * B[kk][j] with i = column of A (row of dW), kk = sample row, j = column of G
+        float av[2][8], bv[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* pa = &As[buf][(8 * lh + j) * kAtbLd + wk * 64 + li];
+            const float* pg = &Gs[buf][(8 * lh + j) * kAtbLd + wn * 64 + li];
+            av[0][j] = pa[0]; av[1][j] = pa[32];
+            bv[0][j] = pg[0]; bv[1][j] = pg[32];
+        }
+        if (do_colsum) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) colsum += Gs[buf][r * kAtbLd + t];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = nb + wn * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + wk * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < g.Kp && n < g.Nw) part[(size_t)k * g.Nw + n] = acc[a][b][r];
+            }
+        }
+    if (do_colsum && nb + t < g.Nw) part[(size_t)g.Kp * g.Nw + nb + t] = colsum;
+}
+
+void launch_gemm_atb(const GemmAtb& g, hipStream_t s) {
+    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    hipLaunchKernelGGL(gemm_atb_kernel, dim3((unsigned)((g.Kp + 127) / 128), (unsigned)((g.Nw + 127) / 128), (unsigned)splits),
+                       dim3(256), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce_grad / relayout / adam: element-wise over one layer
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int train_row_of_blob_row(int kb, int rowmap) {
+    // layer 4: the blob holds [xyz_enc (33) ; hidden (256)] rows, the training layout [hidden ; xyz_enc]
+    if (rowmap == 1) return kb < 33 ? 256 + kb : kb - 33;
+    return kb;
+}
+
+__global__ void reduce_grad_kernel(const ReduceArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (a.K_real + 1) * a.N_real;
+    if (e >= total) return;
+    const int kb = e / a.N_real, n = e % a.N_real;
+    const bool is_bias = kb == a.K_real;
+    const int kt = is_bias ? a.Kp : train_row_of_blob_row(kb, a.rowmap);
+    const float* p = a.partial + (size_t)kt * a.Nw + a.n_src_off + n;
+    const size_t stride = (size_t)(a.Kp + 1) * a.Nw;
+    float s = 0.f;
+    for (int i = 0; i < a.splits; ++i) s += p[i * stride];
+    if (is_bias) a.grad_b[n] = s;
+    else a.grad_w[(size_t)kb * a.N_real + n] = s;
+}
+
+void launch_reduce_grad(const ReduceArgs& a, hipStream_t s) {
+    const int total = (a.K_real + 1) * a.N_real;
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+}
+
+__global__ void relayout_kernel(const RelayoutArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.Kp * a.Np) return;
+    const int kt = e / a.Np, n = e % a.Np;
+    // inverse of train_row_of_blob_row
+    int kb = kt;
+    if (a.rowmap == 1) kb = kt < 256 ? kt + 33 : kt - 256;
+    const bool valid = n < a.N_real && kb >= 0 && kb < a.K_real && (a.rowmap != 1 || kt < 256 + 33);
+    const float v = valid ? a.w[(size_t)kb * a.N_real + n] : 0.f;
+    a.W[(size_t)kt * a.Np + n] = v;
+    a.WT[(size_t)n * a.Kp + kt] = v;
+    if (kt == 0) a.bias[n] = n < a.N_real ? a.b[n] : 0.f;
+}
+
+void launch_relayout(const RelayoutArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(relayout_kernel, dim3((a.Kp * a.Np + 255) / 256), dim3(256), 0, s, a);
+}
+
+__global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, size_t n, float lr_t, float b1, float b2, float eps) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // Keras-2.7 Adam, dense non-amsgrad update (lr_t carries the bias correction; epsilon is not rescaled)
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2,
+                 float eps, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, m, v, g, n, lr_t, beta1,
+                       beta2, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode: sample rows -> xyz / view-direction encodings written straight into the concat buffers
+//   sample_along_rays  src/UtilsCV.py:584-599, get_view_directions :124-143, positional encodings
+//   src/UtilsNeuralRadianceField.py:52-85.  Rows >= N*S (padding to 128) get zeros.
+// ------------------------------------------------------------------------------------------------
+__global__ void train_encode_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                    const float* __restrict__ z, long long M, int S, long long Mp, int n_angles,
+                                    float* __restrict__ C4, float* __restrict__ C8) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mp) return;
+    float* ex = C4 + m * kLdC4 + 256;
+    float* ed = C8 + m * kLdC8 + 256;
+    if (m >= M) {
+        for (int i = 0; i < kXyzPad; ++i) ex[i] = 0.f;
+        for (int i = 0; i < kDirPad; ++i) ed[i] = 0.f;
+        return;
+    }
+    const long long r = m / S;
+    const float zz = z[m];
+    const float kPi = 3.1415927410125732f;
+    const float4 oo = reinterpret_cast<const float4*>(o)[r], dd = reinterpret_cast<const float4*>(d)[r];
+    const float p[3] = {__fadd_rn(oo.x, __fmul_rn(dd.x, zz)), __fadd_rn(oo.y, __fmul_rn(dd.y, zz)),
+                        __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
+    for (int c = 0; c < 3; ++c) {
+        ex[c * 11] = p[c];
+        for (int k = 0; k < 5; ++k) {
+            const float th = __fmul_rn(p[c], kPi * (float)(1 << k));
+            ex[c * 11 + 1 + 2 * k] = sin_shifted(th, 0);
+            ex[c * 11 + 2 + 2 * k] = sin_shifted(th, 1);
+        }
+    }
+    for (int i = 33; i < kXyzPad; ++i) ex[i] = 0.f;
+    const float v3[3] = {dd.x, dd.y, dd.z};
+    const int ncomp = n_angles + 1;
+    for (int c = 0; c < ncomp; ++c) {
+        const float v = n_angles == 2 ? v3[c] : (c == 0 ? v3[0] : v3[2]);
+        for (int k = 0; k < 4; ++k) {
+            const float th = __fmul_rn(v, kPi * (float)(1 << k));
+            ed[c * 8 + 2 * k] = sin_shifted(th, 0);
+            ed[c * 8 + 2 * k + 1] = sin_shifted(th, 1);
+        }
+    }
+    for (int i = ncomp * 8; i < kDirPad; ++i) ed[i] = 0.f;
+}
+
+void launch_train_encode(const float* o, const float* d, const float* z, long long N, int S, long long Mp,
+                         int n_angles, float* C4, float* C8, hipStream_t s) {
+    hipLaunchKernelGGL(train_encode_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, o, d, z, N * S, S,
+                       Mp, n_angles, C4, C8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MSE (Keras MeanSquaredError = mean over all N*3 values, src/NeRF.py:50,151) and its gradient.
+// One workgroup, fixed reduction order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
+                                                  long long n3, float* __restrict__ d_rgb, float* __restrict__ out) {
+    __shared__ float red[256];
+    const float scale = 2.0f / (float)n3;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n3; i += 256) {
+        const float e = rgb[i] - tgt[i];
+        s = fmaf(e, e, s);
+        d_rgb[i] = e * scale;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)n3;
+}
+
+void launch_mse(const float* rgb, const float* target, long long N, float* d_rgb, float* mse_out, hipStream_t s) {
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, s, rgb, target, N * 3, d_rgb, mse_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compositing backward (ray_marching, src/UtilsNeuralRadianceField.py:88-115), one ray per thread,
+// reverse sweep.  With T_i the exclusive transmittance and g_w[i] = dL/dw_i:
+//     dL/dalpha_i = T_i * (g_w[i] - R_i),   R_{i-1} = g_w[i]*alpha_i + (1 - alpha_i)*R_i,   R_{S-1} = 0
+// (no division by 1 - alpha, which is exactly 0 wherever sigma*delta overflows, e.g. the 1e9 last interval).
+// ------------------------------------------------------------------------------------------------
+__global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                     const float* __restrict__ Tin, long long N, int S,
+                                     const float* __restrict__ d_rgb, const float* __restrict__ d_w_ext,
+                                     float* __restrict__ Graw, float* __restrict__ d_z) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const float4* rw = reinterpret_cast<const float4*>(raw) + r * S;
+    float4* gr = reinterpret_cast<float4*>(Graw) + r * S;
+    const float* zr = z + r * S;
+    const float g0 = d_rgb[r * 3 + 0], g1 = d_rgb[r * 3 + 1], g2 = d_rgb[r * 3 + 2];
+    float R = 0.f, prev_dd = 0.f;
+    for (int s = S - 1; s >= 0; --s) {
+        const float4 o = rw[s];
+        const bool last = s + 1 == S;
+        const float delta = last ? 1e9f : zr[s + 1] - zr[s];
+        const float sigma = fmaxf(o.w, 0.f);
+        const float e = expf(-sigma * delta);        // 1 - alpha
+        const float a = 1.0f - e;
+        const float T = Tin[r * S + s];
+        const float c0 = 1.0f / (1.0f + expf(-o.x)), c1 = 1.0f / (1.0f + expf(-o.y)), c2 = 1.0f / (1.0f + expf(-o.z));
+        const float w = a * T;
+        float gw = g0 * c0 + g1 * c1 + g2 * c2;
+        if (d_w_ext) gw += d_w_ext[r * S + s];
+        const float da = T * (gw - R);
+        R = gw * a + e * R;
+        float4 out;
+        out.x = w * g0 * c0 * (1.0f - c0);
+        out.y = w * g1 * c1 * (1.0f - c1);
+        out.z = w * g2 * c2 * (1.0f - c2);
+        out.w = o.w > 0.f ? da * delta * e : 0.f;
+        gr[s] = out;
+        if (d_z) {
+            const float dd = last ? 0.f : da * sigma * e;     // dL/ddelta_s
+            if (!last) d_z[r * S + s + 1] = dd - prev_dd;
+            prev_dd = dd;
+        }
+    }
+    if (d_z) d_z[r * S] = -prev_dd;
+}
+
+void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
+                          const float* d_w_ext, float* Graw, float* d_z, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s, raw, z, T, N, S, d_rgb,
+                       d_w_ext, Graw, d_z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rgb head backward: G9[m][j] = (sum_c Graw[m][c] * W9[j][c]) * LeakyReLU'(H9[m][j])    (layers 9 -> 8)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ Graw, const float* __restrict__ W9,
+                                                       const float* __restrict__ H9, long long M, float alpha,
+                                                       float* __restrict__ G9) {
+    __shared__ float w[128 * 3];
+    for (int i = threadIdx.x; i < 128 * 3; i += 256) w[i] = W9[(i / 3) * 32 + (i % 3)];
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of G9 per thread
+    const long long m = e >> 5;
+    const int j = (int)(e & 31) * 4;
+    if (m >= M) return;
+    const float4 g = reinterpret_cast<const float4*>(Graw)[m];
+    const float4 h = *reinterpret_cast<const float4*>(H9 + m * 128 + j);
+    float4 out;
+    const float hv[4] = {h.x, h.y, h.z, h.w};
+    float ov[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float v = g.x * w[(j + q) * 3 + 0] + g.y * w[(j + q) * 3 + 1] + g.z * w[(j + q) * 3 + 2];
+        ov[q] = hv[q] > 0.f ? v : alpha * v;
+    }
+    out.x = ov[0]; out.y = ov[1]; out.z = ov[2]; out.w = ov[3];
+    *reinterpret_cast<float4*>(G9 + m * 128 + j) = out;
+}
+
+void launch_head_bwd(const float* Graw, const float* W9, const float* H9, long long M, float alpha, float* G9,
+                     hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, s, Graw, W9, H9, M, alpha,
+                       G9);
+}
+
+// ------------------------------------------------------------------------------------------------
+// positional-encoding backward + sample_along_rays backward: d_z[m] += sum_c dL/dp_c * dir_c
+// ------------------------------------------------------------------------------------------------
+__global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __restrict__ o, const float* __restrict__ d,
+                              const float* __restrict__ z, long long M, int S, float* __restrict__ d_z) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const long long r = m / S;
+    const float zz = z[m];
+    const float kPi = 3.1415927410125732f;
+    const float4 oo = reinterpret_cast<const float4*>(o)[r], dd = reinterpret_cast<const float4*>(d)[r];
+    const float p[3] = {__fadd_rn(oo.x, __fmul_rn(dd.x, zz)), __fadd_rn(oo.y, __fmul_rn(dd.y, zz)),
+                        __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
+    const float dv[3] = {dd.x, dd.y, dd.z};
+    const float* g = dA0 + m * kXyzPad;
+    float acc = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        float dp = g[c * 11];
+        for (int k = 0; k < 5; ++k) {
+            const float f = kPi * (float)(1 << k);
+            const float th = __fmul_rn(p[c], f);
+            const float sn = sin_shifted(th, 0), cs = sin_shifted(th, 1);
+            dp += (cs * g[c * 11 + 1 + 2 * k] - sn * g[c * 11 + 2 + 2 * k]) * f;
+        }
+        acc += dp * dv[c];
+    }
+    d_z[m] += acc;
+}
+
+void launch_pe_bwd(const float* dA0, const float* o, const float* d, const float* z, long long N, int S, float* d_z,
+                   hipStream_t s) {
+    const long long M = N * S;
+    if (M <= 0) return;
+    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, dA0, o, d, z, M, S, d_z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse-CDF sampler backward (get_z_vals_from_prob_dist_func, src/UtilsCV.py:502-539): the reference takes
+// gradients through pdf/cdf/gather/lerp/sort (indices are constants), so the fine loss reaches the coarse
+// weights.  One ray per wavefront; the forward quantities are recomputed with the forward kernel's arithmetic
+// (same cdf bits -> same bins and the same sort permutation).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBwdWaves = 4;
+
+__global__ __launch_bounds__(64 * kBwdWaves) void sample_pdf_bwd_kernel(
+    const float* __restrict__ weights, const float* __restrict__ zin, long long N, int S, int Sf,
+    const float* __restrict__ u, uint64_t seed, long long ray_base, const float* __restrict__ d_zf,
+    float* __restrict__ d_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * kBwdWaves + wave;
+    if (ray >= N) return;
+    const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3;
+    const int per_wave = 4 * S4 + 6 * Sf4 + 4;
+    float* cdf = lds + wave * per_wave;
+    float* zc = cdf + S4;
+    float* wv = zc + S4;
+    float* dcdf = wv + S4;
+    float* zn = dcdf + S4;
+    float* span = zn + Sf4;       // z_hi - z_lo
+    float* tt = span + Sf4;
+    float* den = tt + Sf4;        // clamped denominators are stored negated
+    int* ilo = reinterpret_cast<int*>(den + Sf4);
+    int* ihi = ilo + Sf4;
+    float* scal = reinterpret_cast<float*>(ihi + Sf4);   // [0] = sum + eps, [1] = sum_i dpdf_i * w_i
+    const float* wr = weights + ray * S;
+    const float* zr = zin + ray * S;
+    for (int s = lane; s < S; s += 64) { wv[s] = wr[s]; zc[s] = zr[s]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum = __fadd_rn(sum, wv[s]);
+        const float D = __fadd_rn(sum, 1e-7f);
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) {
+            acc = __fadd_rn(acc, __fdiv_rn(wv[s], D));
+            cdf[s] = acc;
+        }
+        scal[0] = D;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float kInf = __builtin_huge_valf();
+    for (int k = lane; k < Sf4; k += 64) {
+        if (k >= Sf) { zn[k] = kInf; continue; }
+        const float uu = u ? u[ray * Sf + k] : philox_uniform(seed, (uint64_t)(ray_base + ray), k, 1u);
+        int lo = 0, hi = S;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] < uu) lo = mid + 1; else hi = mid;
+        }
+        const int b = max(0, lo - 1);
+        const int t = min(S - 1, lo);
+        const float c_lo = cdf[b], c_hi = cdf[t];
+        const int bz = min(max(b, 0), S - 2), tz = min(max(t, 0), S - 2);
+        const float z_lo = __fmul_rn(0.5f, __fadd_rn(zc[bz + 1], zc[bz]));
+        const float z_hi = __fmul_rn(0.5f, __fadd_rn(zc[tz + 1], zc[tz]));
+        float dn = __fsub_rn(c_hi, c_lo);
+        const bool clamped = dn < 1e-5f;
+        dn = clamped ? 1e-5f : dn;
+        const float tv = __fdiv_rn(__fsub_rn(uu, c_lo), dn);
+        zn[k] = __fadd_rn(z_lo, __fmul_rn(tv, __fsub_rn(z_hi, z_lo)));
+        span[k] = __fsub_rn(z_hi, z_lo);
+        tt[k] = tv;
+        den[k] = clamped ? -dn : dn;
+        ilo[k] = b;
+        ihi[k] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // gradient of each unsorted sample = gradient of its slot in the sorted output (stable rank, as forward)
+    float dlo_r[4], dhi_r[4];
+    int nk = 0;
+    for (int k = lane; k < Sf; k += 64, ++nk) {
+        const float v = zn[k];
+        int rank = 0;
+        for (int i = 0; i < Sf4; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(zn + i);
+            rank += (q.x < v || (q.x == v && i + 0 < k)) ? 1 : 0;
+            rank += (q.y < v || (q.y == v && i + 1 < k)) ? 1 : 0;
+            rank += (q.z < v || (q.z == v && i + 2 < k)) ? 1 : 0;
+            rank += (q.w < v || (q.w == v && i + 3 < k)) ? 1 : 0;
+        }
+        const float g = d_zf[ray * Sf + rank];
+        const float dsgn = den[k];
+        const bool clamped = dsgn < 0.f;
+        const float dn = fabsf(dsgn);
+        const float d_t = g * span[k];
+        float dlo = -d_t / dn, dhi = 0.f;
+        if (!clamped) {
+            const float dden = -d_t * tt[k] / dn;
+            dhi = dden;
+            dlo -= dden;
+        }
+        if (nk < 4) { dlo_r[nk] = dlo; dhi_r[nk] = dhi; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // zn / span are dead now: reuse them for the per-sample cdf gradients
+    nk = 0;
+    for (int k = lane; k < Sf; k += 64, ++nk) { zn[k] = dlo_r[nk]; span[k] = dhi_r[nk]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < S; s += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < Sf; ++k) {
+            if (ilo[k] == s) acc += zn[k];
+            if (ihi[k] == s) acc += span[k];
+        }
+        dcdf[s] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float run = 0.f, dot = 0.f;
+        for (int s = S - 1; s >= 0; --s) {     // cumsum backward = reverse cumsum
+            run += dcdf[s];
+            dcdf[s] = run;
+            dot = fmaf(run, wv[s], dot);
+        }
+        scal[1] = dot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float D = scal[0], dot = scal[1];
+    for (int s = lane; s < S; s += 64) d_w[ray * S + s] = dcdf[s] / D - dot / (D * D);
+}
+
+size_t sample_pdf_bwd_lds_bytes(int S, int Sf) {
+    const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3;
+    return (size_t)kBwdWaves * (4 * S4 + 6 * Sf4 + 4) * sizeof(float);
+}
+
+void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
+                           uint64_t seed, long long ray_base, const float* d_zf, float* d_w, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(sample_pdf_bwd_kernel, dim3((unsigned)((N + kBwdWaves - 1) / kBwdWaves)), dim3(64 * kBwdWaves),
+                       sample_pdf_bwd_lds_bytes(S, Sf), s, weights, z, N, S, Sf, u, seed, ray_base, d_zf, d_w);
+}
+
+}  // namespace nerf

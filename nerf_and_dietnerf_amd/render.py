@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FINE, NERF_PRECISION_F16X3,
+from ._lib import (NerfTrainConfig, NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FINE, NERF_PRECISION_F16X3,
                    NERF_PRECISION_FP32, NerfConfig, NerfOutputs)
 
 # configuration key names (src/ConfigurationKeys.py:64-111)
@@ -157,6 +157,59 @@ class Context:
         n = C.c_int64()
         _lib.check(self.lib.nerf_ctx_read_nonfinite(self.h, C.byref(n)))
         return n.value
+
+    # ---- training (NeRF.train_step, src/NeRF.py:136-178) ----
+    def train_begin(self, learning_rate: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
+                    sampler_gradient: bool = True) -> None:
+        """Adam(lr) as model.compile(optimizer=Adam(optimizer_lr)) (src/ExecutionRun.py:226-227)."""
+        cfg = NerfTrainConfig(learning_rate, beta_1, beta_2, epsilon, 1 if sampler_gradient else 0)
+        _lib.check(self.lib.nerf_train_begin(self.h, C.byref(cfg)))
+
+    def train_end(self) -> None:
+        _lib.check(self.lib.nerf_train_end(self.h))
+
+    def train_set_learning_rate(self, learning_rate: float) -> None:
+        _lib.check(self.lib.nerf_train_set_learning_rate(self.h, learning_rate))
+
+    def _train_inputs(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse, u_fine):
+        arr = self._arrays(rays_orig, rays_dirs, real_rgb)
+        n = int(rays_orig.shape[0])
+        ptrs = (arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4)), arr.inp(real_rgb, (n, 3)))
+        uc = arr.inp(u_coarse, (n, n_c)) if u_coarse is not None else None
+        uf = arr.inp(u_fine, (n, n_f)) if (u_fine is not None and n_f > 0) else None
+        return arr, n, ptrs, uc, uf
+
+    def train_step(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0,
+                   want_metrics=True) -> Optional[Dict[str, float]]:
+        """One optimizer step on a batch of rays -> {"loss", "psnr_coarse", "psnr_fine"} (src/NeRF.py:166-177)."""
+        arr, n, (po, pd, pt), uc, uf = self._train_inputs(rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse, u_fine)
+        m = (C.c_float * 3)()
+        _lib.check(self.lib.nerf_train_step(self.h, po, pd, pt, n, n_c, n_f, uc, uf, seed,
+                                            C.cast(m, C.c_void_p) if want_metrics else None, arr.mem))
+        return _metrics(m, n_f > 0 and self.loaded[1]) if want_metrics else None
+
+    def train_gradients(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0):
+        """Gradients without the update -> (metrics, grad_coarse blob, grad_fine blob | None)."""
+        arr, n, (po, pd, pt), uc, uf = self._train_inputs(rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse, u_fine)
+        fine = n_f > 0 and self.loaded[1]
+        gc, pgc = arr.out((self.blob_size(),))
+        gf, pgf = arr.out((self.blob_size(),)) if fine else (None, None)
+        m = (C.c_float * 3)()
+        _lib.check(self.lib.nerf_train_gradients(self.h, po, pd, pt, n, n_c, n_f, uc, uf, seed, pgc, pgf,
+                                                 C.cast(m, C.c_void_p), arr.mem))
+        return _metrics(m, fine), gc, gf
+
+    def train_apply(self, grad_coarse=None, grad_fine=None) -> None:
+        """Adam update from the given gradient blobs (e.g. after an all-reduce), or from the ctx's own."""
+        arr = self._arrays(grad_coarse, grad_fine)
+        n = self.blob_size()
+        _lib.check(self.lib.nerf_train_apply(self.h, arr.inp(grad_coarse, (n,)), arr.inp(grad_fine, (n,)), arr.mem))
+
+    def get_weights(self, which: int) -> np.ndarray:
+        """Current weights as a flat blob in Keras ``get_weights()`` order."""
+        out = np.empty(self.blob_size(), np.float32)
+        _lib.check(self.lib.nerf_get_weights(self.h, which, out.ctypes.data, out.size, NERF_MEM_HOST))
+        return out
 
     def enable_timing(self, on: bool = True) -> None:
         _lib.check(self.lib.nerf_ctx_enable_timing(self.h, int(on)))
@@ -311,6 +364,13 @@ class Context:
         return res if want_depth else res[:6]
 
 
+def _metrics(m, fine: bool) -> Dict[str, float]:
+    out = {"loss": float(m[0]), "psnr_coarse": float(m[1])}
+    if fine:
+        out["psnr_fine"] = float(m[2])
+    return out
+
+
 def _reshape(x, shape):
     return x.reshape(shape)
 
@@ -323,7 +383,7 @@ class NetHandle:
 
 
 class NeRF:
-    """Mirror of the reference model class (src/NeRF.py:22-246), forward/render path only."""
+    """Mirror of the reference model class (src/NeRF.py:22-246): render path and train_step."""
 
     def __init__(self, net_config: Dict, render_config: Dict, near_boundary: float, far_boundary: float,
                  device: int = 0, precision: str = "fp32"):
@@ -362,6 +422,40 @@ class NeRF:
         """src/NeRF.py:342-351."""
         from pathlib import Path
         return Path(save_location) / "saved_weights" / "NeRF_model_epoch_{:03}.h5".format(epoch_number)
+
+    # ---- training: model.compile(optimizer=Adam(lr)) + train_step (src/ExecutionRun.py:226-227, src/NeRF.py:136-178)
+    def compile(self, optimizer_lr: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
+                sampler_gradient: bool = True) -> None:
+        self.ctx.train_begin(optimizer_lr, beta_1, beta_2, epsilon, sampler_gradient)
+        self._train_calls = 0
+
+    def train_step(self, data, *, u_coarse=None, u_fine=None, seed=None, group=None) -> Dict[str, float]:
+        """``data`` = (rays_orig (N,4), rays_dirs (N,4), real_rgb (N,3)) -> {"loss", "psnr_coarse"[, "psnr_fine"]}.
+
+        Under an initialised torch.distributed ``group`` every rank passes its own shard of the batch; the
+        gradient blobs are averaged with one all-reduce each (RCCL) before the identical Adam update."""
+        rays_orig, rays_dirs, real_rgb = data
+        n_f = self.n_render_samples_fine if self.model_fine else 0
+        if seed is None:
+            seed = self.seed + 7919 * self._train_calls
+        self._train_calls += 1
+        from .sharding import dist_world
+        world = dist_world(group)
+        if world == 1:
+            return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
+                                       u_fine, seed)
+        from .sharding import allreduce_mean
+        metrics, gc, gf = self.ctx.train_gradients(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f,
+                                                   u_coarse, u_fine, seed)
+        gc = allreduce_mean(gc, group)
+        gf = allreduce_mean(gf, group) if gf is not None else None
+        self.ctx.train_apply(gc, gf)
+        return metrics
+
+    def get_weights(self):
+        """(coarse blob, fine blob | None), Keras ``get_weights()`` order."""
+        return (self.ctx.get_weights(NERF_NET_COARSE),
+                self.ctx.get_weights(NERF_NET_FINE) if self.model_fine and self.ctx.loaded[1] else None)
 
     def call(self, inputs, training=None, mask=None):
         rays_orig, rays_dirs = inputs

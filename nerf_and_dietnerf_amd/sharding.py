@@ -54,3 +54,34 @@ def render_image_sharded(model, c2w, fov, h, w, group=None, rgb_only=True, **kw)
         full = gather_slabs(o, total, group)
         res.append(full.reshape((h, w) + tuple(full.shape[1:])))
     return tuple(res)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training: every rank computes the gradients of its shard of the ray batch, the two
+# gradient blobs (2 x 2.06 MB) are averaged with one all-reduce each, every rank applies the same Adam step.
+# ---------------------------------------------------------------------------------------------
+def dist_world(group=None) -> int:
+    """World size of ``group`` (1 when torch.distributed is absent or not initialised)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 1
+    if not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group)
+
+
+def allreduce_mean(blob, group=None):
+    """Mean of a flat fp32 blob over the ranks of ``group`` (numpy in -> numpy out, CUDA tensor in place)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    is_np = isinstance(blob, np.ndarray)
+    t = torch.from_numpy(blob) if is_np else blob
+    dev = t.device
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        t = t.cpu()                      # one-GPU rehearsal: gloo has no CUDA all-reduce
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= world
+    return t.numpy() if is_np else t.to(dev)

@@ -1,0 +1,151 @@
+"""CPU oracle for the training step -- TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+Restates `NeRF.train_step` (src/NeRF.py:136-178) with torch-CPU autograd standing in for
+`tf.GradientTape`, so that the hand-written HIP backward can be checked against automatic differentiation:
+
+    z            = get_z_values(near, far, N, 1, Sc)                 src/NeRF.py:146-147
+    coarse pass  = render_rays(model_coarse, o, d, z)[:2]            src/NeRF.py:150
+    loss         = MSE(real_rgb, coarse_rgb)                         src/NeRF.py:151
+    z_from_dist  = get_z_vals_from_prob_dist_func(w_coarse, z, Sf)   src/NeRF.py:155   (NO stop_gradient:
+                   the fine loss reaches the coarse network through the sampler, src/UtilsCV.py:512-537)
+    fine pass    = render_rays(model_fine, o, d, z_from_dist)[:2]    src/NeRF.py:156   (Sf samples only)
+    loss        += MSE(real_rgb, fine_rgb)                           src/NeRF.py:157
+    gradients -> Adam (Keras 2.7 defaults beta_1=.9, beta_2=.999, epsilon=1e-7; src/ExecutionRun.py:226)
+    metrics      = loss, psnr_coarse, psnr_fine                      src/NeRF.py:169-177
+
+Pinning status: the forward half is checked against oracle/nerf_oracle.py (itself pinned by the shipped
+checkpoint + recorded PSNRs); the backward half is torch autograd of that forward.  No reference test or
+fixture holds gradients: "parity unpinned" beyond that.  float64 by default (truth for tolerance tests).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import nerf_oracle as O
+
+EPS = 1e-7
+
+
+def blob_to_params(blob: np.ndarray, dtype=torch.float64, **kw) -> List[torch.Tensor]:
+    """Flat Keras-order blob -> [k0,b0,...,k10,b10] leaf tensors with requires_grad."""
+    out = []
+    for k, b in O.unpack_blob(np.asarray(blob, np.float32), **kw):
+        out.append(torch.tensor(k, dtype=dtype, requires_grad=True))
+        out.append(torch.tensor(b, dtype=dtype, requires_grad=True))
+    return out
+
+
+def params_to_blob(tensors: Sequence[torch.Tensor]) -> np.ndarray:
+    return np.concatenate([t.detach().cpu().numpy().astype(np.float64).ravel() for t in tensors])
+
+
+def _pe(x: torch.Tensor, n_enc: int, passthrough: bool) -> torch.Tensor:
+    """src/UtilsNeuralRadianceField.py:52-85: theta = (2^k * pi_f32) * x, [x,] sin0,cos0,... per component."""
+    pi32 = float(np.float32(math.pi))
+    pow2 = torch.tensor([float(np.float32(2.0 ** k) * np.float32(pi32)) for k in range(n_enc)], dtype=x.dtype)
+    th = x[..., None] * pow2                                        # (M,C,L)
+    st = torch.stack((torch.sin(th), torch.cos(th)), dim=-1).reshape(x.shape[0], x.shape[1], 2 * n_enc)
+    if passthrough:
+        st = torch.cat([x[..., None], st], dim=-1)
+    return st.reshape(x.shape[0], -1)
+
+
+def _mlp(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float):
+    """src/NeRF.py:316-339."""
+    lrelu = lambda t: torch.nn.functional.leaky_relu(t, alpha)
+    h = lrelu(xyz_enc @ p[0] + p[1])
+    for i in (1, 2, 3):
+        h = lrelu(h @ p[2 * i] + p[2 * i + 1])
+    h = lrelu(torch.cat([xyz_enc, h], -1) @ p[8] + p[9])
+    for i in (5, 6, 7):
+        h = lrelu(h @ p[2 * i] + p[2 * i + 1])
+    hd = torch.cat([h, dir_enc], -1)
+    h8 = lrelu(hd @ p[16] + p[17])
+    rgb = h8 @ p[18] + p[19]
+    sigma = hd @ p[20] + p[21]
+    return torch.cat([rgb, sigma], -1)
+
+
+def _render_rays(p, o, d, z, n_xyz, n_dir, n_angles, alpha):
+    """src/UtilsNeuralRadianceField.py:181-211 + ray_marching :88-115 -> (rgb (N,3), weights (N,S))."""
+    n, s = z.shape
+    pts = (o[:, None, :3] + d[:, None, :3] * z[..., None]).reshape(-1, 3)
+    comps = [0, 1, 2] if n_angles == 2 else [0, 2]                   # src/UtilsCV.py:124-143
+    view = d[:, comps][:, None, :].expand(n, s, len(comps)).reshape(-1, len(comps))
+    raw = _mlp(p, _pe(pts, n_xyz, True), _pe(view, n_dir, False), alpha).reshape(n, s, 4)
+    sigma = torch.relu(raw[..., 3])
+    c = torch.sigmoid(raw[..., :3])
+    delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 1e9, dtype=z.dtype)], -1)
+    a = 1.0 - torch.exp(-sigma * delta)
+    T = torch.cumprod(torch.cat([torch.ones((n, 1), dtype=z.dtype), 1.0 - a[:, :-1]], -1), -1)   # exclusive
+    w = a * T
+    return (w[..., None] * c).sum(1), w
+
+
+def _sample_pdf(w, z, u):
+    """src/UtilsCV.py:502-539, differentiable in ``w`` exactly as the TF graph is (indices are constants)."""
+    s = w.shape[1]
+    pdf = w / (w.sum(-1, keepdim=True) + EPS)
+    cdf = torch.cumsum(pdf, -1)
+    idx = torch.searchsorted(cdf.detach().contiguous(), u.contiguous(), right=False)
+    lo = torch.clamp(idx - 1, min=0)
+    hi = torch.clamp(idx, max=s - 1)
+    c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    mid = 0.5 * (z[:, 1:] + z[:, :-1])
+    z_lo = torch.gather(mid, 1, torch.clamp(lo, 0, s - 2))
+    z_hi = torch.gather(mid, 1, torch.clamp(hi, 0, s - 2))
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.full_like(den, 1e-5), den)
+    t = (u - c_lo) / den
+    zs = z_lo + t * (z_hi - z_lo)
+    return torch.sort(zs, -1).values
+
+
+def train_forward(pc, pf, rays_o, rays_d, target, near, far, u_c, u_f, n_xyz=5, n_dir=4, n_angles=2,
+                  alpha=0.05, sampler_grad=True, dtype=torch.float64):
+    """-> (loss, mse_coarse, mse_fine|None, z_fine|None) as torch scalars/tensors (graph attached)."""
+    o = torch.tensor(np.asarray(rays_o), dtype=dtype)
+    d = torch.tensor(np.asarray(rays_d), dtype=dtype)
+    tgt = torch.tensor(np.asarray(target), dtype=dtype)
+    z = torch.tensor(O.get_z_values(near, far, np.asarray(u_c, np.float32)), dtype=dtype)
+    rgb_c, w_c = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha)
+    mse_c = ((rgb_c - tgt) ** 2).mean()
+    loss, mse_f, z_f = mse_c, None, None
+    if pf is not None:
+        z_f = _sample_pdf(w_c if sampler_grad else w_c.detach(), z, torch.tensor(np.asarray(u_f), dtype=dtype))
+        rgb_f, _ = _render_rays(pf, o, d, z_f, n_xyz, n_dir, n_angles, alpha)
+        mse_f = ((rgb_f - tgt) ** 2).mean()
+        loss = loss + mse_f
+    return loss, mse_c, mse_f, z_f
+
+
+def train_gradients(blob_c, blob_f, rays_o, rays_d, target, near, far, u_c, u_f, dtype=torch.float64, **kw):
+    """-> dict(loss, psnr_coarse, psnr_fine, grad_coarse (blob), grad_fine (blob|None), z_fine)."""
+    shape_kw = {k: kw[k] for k in ("n_pos_enc_xyz", "n_pos_enc_dir", "n_angles") if k in kw}
+    fw = dict(n_xyz=kw.get("n_pos_enc_xyz", 5), n_dir=kw.get("n_pos_enc_dir", 4), n_angles=kw.get("n_angles", 2),
+              alpha=kw.get("alpha", 0.05), sampler_grad=kw.get("sampler_grad", True), dtype=dtype)
+    pc = blob_to_params(blob_c, dtype, **shape_kw)
+    pf = blob_to_params(blob_f, dtype, **shape_kw) if blob_f is not None else None
+    loss, mse_c, mse_f, z_f = train_forward(pc, pf, rays_o, rays_d, target, near, far, u_c, u_f, **fw)
+    loss.backward()
+    g = lambda ps: np.concatenate([(t.grad if t.grad is not None else torch.zeros_like(t)).numpy().ravel()
+                                   for t in ps])
+    psnr = lambda m: float(-10.0 * math.log10(float(m.detach())))             # src/UtilsNeuralRadianceField.py:123-132
+    return dict(loss=float(loss.detach()), psnr_coarse=psnr(mse_c), psnr_fine=psnr(mse_f) if mse_f is not None else None,
+                grad_coarse=g(pc), grad_fine=g(pf) if pf is not None else None,
+                z_fine=None if z_f is None else z_f.detach().numpy())
+
+
+def adam_update(w: np.ndarray, m: np.ndarray, v: np.ndarray, g: np.ndarray, t: int, lr: float,
+                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7):
+    """Keras-2.7 Adam (`optimizer_v2/adam.py`, non-amsgrad dense update), step t = iterations+1 (1-based):
+        lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t); m,v moments; w -= lr_t*m/(sqrt(v)+eps).  float64 maths."""
+    w, m, v, g = (np.asarray(a, np.float64) for a in (w, m, v, g))
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v

@@ -1,0 +1,198 @@
+"""Parity of the HIP training step (through the C ABI: nerf_train_*) against oracle/train_oracle.py
+(torch-CPU autograd of the reference's train_step in float64).
+
+Tolerances.  The network is piecewise linear (LeakyReLU): a pre-activation that the fp32 forward puts on the
+other side of zero than the float64 oracle changes one mask entry from 1 to alpha, i.e. a DISCRETE change of
+the gradient.  With ~10 pre-activations per layer within 1e-5 of zero at these sizes (measured), single flips
+happen; the oracle's own fp32-vs-fp64 difference is 5e-6 (fine net) to 2e-4 (coarse net through the sampler)
+of max|g|, and single flips on these ~1000-row problems reach 3e-3.  So the arithmetic is pinned with
+leaky_relu_alpha = 1 (smooth network: 2e-5 of max|g|), and the masks with the reference's alpha = 0.05 at
+5e-2 of max|g| and cosine > 0.999.  Adam itself is checked on identical gradients.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(oracle, n, seed=0, hw=8):
+    rng = np.random.default_rng(seed)
+    c2w = oracle.get_sphere_matrix(1.0, -20, 30, 0).astype(np.float32)
+    d = oracle.get_rays_directions(hw, hw, 0.46, c2w).reshape(-1, 4)
+    idx = rng.choice(d.shape[0], n, replace=n > d.shape[0])
+    return np.tile(c2w[:, 3], (n, 1)).astype(np.float32), np.ascontiguousarray(d[idx]), rng
+
+
+def _problem(oracle, golden_ckpt, n=48, sc=16, sf=24, seed=0):
+    o, d, rng = _rays(oracle, n, seed)
+    return dict(o=o, d=d, u_c=rng.random((n, sc), dtype=np.float32), u_f=rng.random((n, sf), dtype=np.float32),
+                tgt=rng.random((n, 3), dtype=np.float32), sc=sc, sf=sf, near=float(golden_ckpt["near"]),
+                far=float(golden_ckpt["far"]), bc=golden_ckpt["blob_coarse"], bf=golden_ckpt["blob_fine"])
+
+
+def _ctx(p, fine=True, **kw):
+    import nerf_and_dietnerf_amd as N
+    ctx = N.Context(near=p["near"], far=p["far"], **kw)
+    ctx.load_weights(0, p["bc"])
+    if fine:
+        ctx.load_weights(1, p["bf"])
+    return ctx
+
+
+def _relerr(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _cos(a, b):
+    a = a.astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def test_gradients_coarse_only(oracle, golden_ckpt):
+    """No fine network (n_render_samples_fine == 0, src/NeRF.py:36-39,153): loss = coarse MSE alone."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt)
+    ctx = _ctx(p, fine=False)
+    ctx.train_begin(5e-4)
+    m, gc, gf = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], 0, p["u_c"])
+    r = T.train_gradients(p["bc"], None, p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], None)
+    assert gf is None and "psnr_fine" not in m
+    assert abs(m["loss"] - r["loss"]) <= 1e-6 * r["loss"] + 1e-7
+    assert abs(m["psnr_coarse"] - r["psnr_coarse"]) <= 1e-4
+    assert _relerr(gc, r["grad_coarse"]) <= 1e-2 and _cos(gc, r["grad_coarse"]) > 0.9999
+    ctx.close()
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.05])
+@pytest.mark.parametrize("sampler_gradient", [False, True])
+def test_gradients_coarse_and_fine(oracle, golden_ckpt, sampler_gradient, alpha):
+    """alpha = 1 makes the network smooth (LeakyReLU = identity): every GEMM, the heads, compositing, positional
+    encoding and sampler backward are then checked at 2e-4 of max|g| (measured 1e-5..4e-5, the fp32 floor: the
+    float32 oracle differs from the float64 one by 2.4e-5..2.8e-5 here).  alpha = 0.05 (the reference's value) adds
+    the LeakyReLU' masks, where single fp32-vs-float64 sign flips of near-zero pre-activations move a gradient
+    entry by ~1/rows of its value, and one flip in the fine pass moves one ray's sampler gradient, i.e. ~1/N of
+    the coarse gradient (N = 48 rays here: 2e-2 measured): bar 5e-2 of max|g| and cosine > 0.999 -- a wrong mask
+    would be an O(1) error."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt)
+    ctx = _ctx(p, leaky_relu_alpha=alpha)
+    ctx.train_begin(5e-4, sampler_gradient=sampler_gradient)
+    m, gc, gf = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
+                          sampler_grad=sampler_gradient, alpha=alpha)
+    assert abs(m["loss"] - r["loss"]) <= 2e-6 * r["loss"]
+    assert abs(m["psnr_coarse"] - r["psnr_coarse"]) <= 1e-4 and abs(m["psnr_fine"] - r["psnr_fine"]) <= 1e-4
+    assert np.isfinite(gc).all() and np.isfinite(gf).all()
+    tol, cos_min = (2e-4, 0.9999999) if alpha == 1.0 else (5e-2, 0.999)
+    assert _relerr(gc, r["grad_coarse"]) <= tol and _cos(gc, r["grad_coarse"]) > cos_min
+    assert _relerr(gf, r["grad_fine"]) <= tol and _cos(gf, r["grad_fine"]) > cos_min
+    # the reference's sampler term is a large part of the coarse gradient: make sure it is really there
+    if sampler_gradient and alpha != 1.0:
+        r0 = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
+                               sampler_grad=False, alpha=alpha)
+        assert np.linalg.norm(gc - r0["grad_coarse"]) > 0.3 * np.linalg.norm(gc)
+    ctx.close()
+
+
+def test_gradients_device_rng_and_odd_sizes(oracle, golden_ckpt):
+    """u = NULL: jitter and inverse-CDF draws from the on-device Philox (same counters in the forward sampler
+    and in its backward); N*S not a multiple of the 128-row GEMM tile; n_angles = 1 network."""
+    from oracle import train_oracle as T
+    import nerf_and_dietnerf_amd as N
+    n, sc, sf, seed = 37, 11, 19, 1234
+    o, d, rng = _rays(oracle, n, 3)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    kw = dict(n_pos_enc_xyz=5, n_pos_enc_dir=4, n_angles=1)
+    bc, bf = N.glorot_blob(1, **kw), N.glorot_blob(2, **kw)
+    # Glorot nets give sigma ~ 0 everywhere; lift the sigma bias so that the compositing is not trivial
+    bc[-1] = bf[-1] = 2.0
+    near, far = 0.5, 2.5
+    ctx = N.Context(near=near, far=far, n_angles=1)
+    ctx.load_weights(0, bc)
+    ctx.load_weights(1, bf)
+    ctx.train_begin(1e-3)
+    m, gc, gf = ctx.train_gradients(o, d, tgt, sc, sf, None, None, seed)
+    ray = np.arange(n)
+    u_c = oracle.philox_uniform(seed, ray, sc, 0)
+    u_f = oracle.philox_uniform(seed, ray, sf, 1)
+    r = T.train_gradients(bc, bf, o, d, tgt, near, far, u_c, u_f, n_angles=1)
+    assert abs(m["loss"] - r["loss"]) <= 2e-6 * r["loss"]
+    assert _relerr(gc, r["grad_coarse"]) <= 5e-2 and _cos(gc, r["grad_coarse"]) > 0.999
+    assert _relerr(gf, r["grad_fine"]) <= 5e-2 and _cos(gf, r["grad_fine"]) > 0.999
+    ctx.close()
+
+
+def test_adam_update_matches_keras_formula(oracle, golden_ckpt):
+    """nerf_train_apply on caller-supplied gradients == Keras-2.7 Adam (oracle.adam_update), three steps."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt)
+    ctx = _ctx(p)
+    lr = 5e-4
+    ctx.train_begin(lr)
+    rng = np.random.default_rng(5)
+    w = [p["bc"].astype(np.float64), p["bf"].astype(np.float64)]
+    mm = [np.zeros_like(w[0]), np.zeros_like(w[1])]
+    vv = [np.zeros_like(w[0]), np.zeros_like(w[1])]
+    for t in range(1, 4):
+        g = [(rng.standard_normal(w[0].size) * 10.0 ** rng.uniform(-8, -1, w[0].size)).astype(np.float32)
+             for _ in range(2)]
+        ctx.train_apply(g[0], g[1])
+        for i in range(2):
+            w[i], mm[i], vv[i] = T.adam_update(w[i], mm[i], vv[i], g[i], t, lr)
+    for i in range(2):
+        got = ctx.get_weights(i)
+        step = np.abs(got - (p["bc"], p["bf"])[i]).max()
+        assert 0.5 * lr < step <= 3.5 * lr
+        assert np.abs(got - w[i]).max() <= 4e-7 * max(1.0, np.abs(w[i]).max())     # < 0.1 % of one step
+    ctx.close()
+
+
+def test_train_steps_reduce_loss_and_render_sees_new_weights(oracle, golden_ckpt):
+    """A few optimizer steps on a fixed batch lower the loss; the render path then uses the trained weights
+    (operand streams re-packed lazily) and agrees with the oracle run on nerf_get_weights()."""
+    import nerf_and_dietnerf_amd as N
+    p = _problem(oracle, golden_ckpt, n=64, sc=16, sf=24, seed=2)
+    p["tgt"][:] = np.array([0.9, 0.2, 0.1], np.float32)
+    ctx = _ctx(p)
+    ctx.train_begin(5e-4)
+    losses = [ctx.train_step(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])["loss"]
+              for _ in range(25)]
+    assert all(math.isfinite(x) for x in losses)
+    assert losses[-1] < 0.5 * losses[0]
+    out = ctx.render(p["o"], p["d"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    wc, wf = ctx.get_weights(0), ctx.get_weights(1)
+    assert np.abs(wc - p["bc"]).max() > 1e-3
+    ref = oracle.render(oracle.unpack_blob(wc), oracle.unpack_blob(wf), p["o"], p["d"], p["near"], p["far"],
+                        p["u_c"], p["u_f"])
+    assert np.abs(out[0] - ref[0]).max() <= 1e-4
+    ctx.train_end()
+    out2 = ctx.render(p["o"], p["d"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    np.testing.assert_array_equal(out[0], out2[0])
+    ctx.close()
+
+
+def test_nerf_mirror_train_step_and_full_batch_timing(oracle, golden_ckpt, capsys):
+    """NeRF.compile + NeRF.train_step (the reference's names) at the reference's batch: 4096 rays, 64 + 128."""
+    import time
+    import nerf_and_dietnerf_amd as N
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
+               "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
+    ren_cfg = {"n_render_samples_coarse": 64, "n_render_samples_fine": 128}
+    m = N.NeRF(net_cfg, ren_cfg, float(golden_ckpt["near"]), float(golden_ckpt["far"]))
+    m.set_weights(golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
+    m.compile(5e-4)
+    o, d, rng = _rays(oracle, 4096, 7, hw=64)
+    tgt = rng.random((4096, 3), dtype=np.float32)
+    first = m.train_step((o, d, tgt))
+    assert set(first) == {"loss", "psnr_coarse", "psnr_fine"} and math.isfinite(first["loss"])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        last = m.train_step((o, d, tgt))
+    dt = (time.perf_counter() - t0) / 5
+    assert last["loss"] < first["loss"]
+    with capsys.disabled():
+        print(f"\n[train] 4096 rays x (64 coarse + 128 fine): {dt * 1e3:.1f} ms/step (host arrays in, metrics out)")
+    m.ctx.close()

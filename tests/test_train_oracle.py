@@ -1,0 +1,147 @@
+"""CPU checks of the training oracle (oracle/train_oracle.py) and of the host-side training logic.
+
+The oracle's forward must equal the pinned render oracle (oracle/nerf_oracle.py); its backward is torch
+autograd, cross-checked here by central finite differences in float64 -- including weights of the COARSE
+network whose only path to the fine loss is the sampler (the reference has no stop_gradient there)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _setup(oracle, golden_ckpt, n=12, sc=8, sf=10):
+    rng = np.random.default_rng(0)
+    c2w = oracle.get_sphere_matrix(1.0, -20, 30, 0).astype(np.float32)
+    d = oracle.get_rays_directions(6, 6, 0.46, c2w).reshape(-1, 4)[:n]
+    o = np.tile(c2w[:, 3], (n, 1)).astype(np.float32)
+    return dict(o=o, d=d, u_c=rng.random((n, sc), dtype=np.float32), u_f=rng.random((n, sf), dtype=np.float32),
+                tgt=rng.random((n, 3), dtype=np.float32), near=float(golden_ckpt["near"]), far=float(golden_ckpt["far"]),
+                bc=golden_ckpt["blob_coarse"], bf=golden_ckpt["blob_fine"])
+
+
+def test_train_oracle_forward_equals_render_oracle(oracle, golden_ckpt):
+    from oracle import train_oracle as T
+    p = _setup(oracle, golden_ckpt)
+    lc, lf = oracle.unpack_blob(p["bc"]), oracle.unpack_blob(p["bf"])
+    z = oracle.get_z_values(p["near"], p["far"], p["u_c"])
+    rc = oracle.render_rays(lc, p["o"], p["d"], z)
+    zf = oracle.get_z_vals_from_prob_dist_func(rc[1], z, p["u_f"])
+    rf = oracle.render_rays(lf, p["o"], p["d"], zf)                     # fine pass on the NEW samples only
+    mse_c, mse_f = np.mean((rc[0] - p["tgt"]) ** 2), np.mean((rf[0] - p["tgt"]) ** 2)
+    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"])
+    assert abs(r["loss"] - (mse_c + mse_f)) <= 1e-6
+    assert abs(r["psnr_coarse"] + 10 * math.log10(mse_c)) <= 1e-4
+    assert abs(r["psnr_fine"] + 10 * math.log10(mse_f)) <= 1e-4
+    assert np.abs(r["z_fine"] - zf).max() <= 1e-5
+
+
+def test_train_oracle_gradients_by_finite_differences(oracle, golden_ckpt):
+    from oracle import train_oracle as T
+    p = _setup(oracle, golden_ckpt)
+    args = (p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"])
+    r = T.train_gradients(p["bc"], p["bf"], *args)
+
+    def loss_at(bc64, bf64):
+        pc = [t.detach() for t in T.blob_to_params(p["bc"])]
+        pf = [t.detach() for t in T.blob_to_params(p["bf"])]
+        for params, blob in ((pc, bc64), (pf, bf64)):
+            off = 0
+            for t in params:
+                t.copy_(torch.tensor(blob[off:off + t.numel()].reshape(t.shape)))
+                off += t.numel()
+        with torch.no_grad():
+            return float(T.train_forward(pc, pf, *args)[0])
+
+    bc64, bf64 = p["bc"].astype(np.float64), p["bf"].astype(np.float64)
+    rng = np.random.default_rng(1)
+    # the largest-gradient entries (well above the finite-difference noise) + the sigma bias
+    for which, g in ((0, r["grad_coarse"]), (1, r["grad_fine"])):
+        picks = list(np.argsort(-np.abs(g))[:3]) + [g.size - 1] + list(rng.choice(g.size, 2))
+        for i in picks:
+            h = 1e-5
+            blobs = [bc64.copy(), bf64.copy()]
+            blobs[which][i] += h
+            up = loss_at(*blobs)
+            blobs[which][i] -= 2 * h
+            dn = loss_at(*blobs)
+            fd = (up - dn) / (2 * h)
+            # central differences straddle LeakyReLU / relu / bin-selection kinks: a structural check, 1 % bar
+            assert abs(fd - g[i]) <= 1e-5 * np.abs(g).max() + 1e-2 * abs(g[i]), (which, i, fd, g[i])
+    # and the sampler term is not a rounding artefact
+    r0 = T.train_gradients(p["bc"], p["bf"], *args, sampler_grad=False)
+    assert np.linalg.norm(r["grad_coarse"] - r0["grad_coarse"]) > 0.1 * np.linalg.norm(r["grad_coarse"])
+    np.testing.assert_allclose(r["grad_fine"], r0["grad_fine"], rtol=0, atol=1e-12)
+
+
+def test_adam_known_answer():
+    """Keras-2.7 Adam by hand for one scalar, two steps (lr 0.1, defaults)."""
+    from oracle import train_oracle as T
+    w, m, v = np.array([1.0]), np.zeros(1), np.zeros(1)
+    w, m, v = T.adam_update(w, m, v, np.array([0.5]), 1, 0.1)
+    # step 1: m = .05, v = 2.5e-4, lr_t = .1*sqrt(.001)/.1 -> w -= lr_t*m/(sqrt(v)+1e-7) = 0.1*(1 - tiny)
+    assert abs(w[0] - (1.0 - 0.1 * 0.05 * math.sqrt(0.001) / 0.1 / (math.sqrt(2.5e-4) + 1e-7))) < 1e-15
+    assert abs(w[0] - 0.9) < 1e-6
+    w, m, v = T.adam_update(w, m, v, np.array([-0.25]), 2, 0.1)
+    m2 = 0.9 * 0.05 + 0.1 * -0.25
+    v2 = 0.999 * 2.5e-4 + 0.001 * 0.0625
+    lr2 = 0.1 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert abs(m[0] - m2) < 1e-15 and abs(v[0] - v2) < 1e-15
+    w1 = 1.0 - 0.1 * math.sqrt(0.001) / 0.1 * 0.05 / (math.sqrt(2.5e-4) + 1e-7)
+    assert abs(w[0] - (w1 - lr2 * m2 / (math.sqrt(v2) + 1e-7))) < 1e-15
+
+
+class _FakeCtx:
+    """Stands in for Context in the data-parallel step: gradient = mean of the shard's targets."""
+    loaded = [True, True]
+
+    def __init__(self):
+        self.applied = None
+
+    def train_begin(self, *a, **k):
+        pass
+
+    def train_gradients(self, o, d, rgb, n_c, n_f, u_c, u_f, seed):
+        g = np.full(8, float(np.mean(rgb)), np.float32)
+        return {"loss": float(np.mean(rgb))}, g, g * 2
+
+    def train_apply(self, gc, gf):
+        self.applied = (np.array(gc), np.array(gf))
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nerf_and_dietnerf_amd as N
+        m = N.NeRF.__new__(N.NeRF)
+        m.ctx, m.model_fine, m.n_render_samples_coarse, m.n_render_samples_fine = _FakeCtx(), object(), 4, 4
+        m.seed, m._train_calls = 0, 0
+        full = np.arange(24, dtype=np.float32).reshape(8, 3)
+        shard = full[rank * 4:(rank + 1) * 4]
+        m.train_step((np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), shard))
+        q.put((rank, m.ctx.applied[0].tolist(), m.ctx.applied[1].tolist(), float(full.mean())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_averages_gradients_gloo():
+    """world_size 2 on CPU: every rank applies the mean of the ranks' gradient blobs (== full-batch gradient
+    for equal shards, MSE being a mean over rays)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, gc, gf, mean in res:
+        assert np.allclose(gc, mean) and np.allclose(gf, 2 * mean), (rank, gc, mean)
