@@ -26,10 +26,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 constexpr int kLdsLd = 20;   // floats per staged row of 16 (80 B: keeps float4 alignment, spreads banks)
 
+// One k-step (16) of the workgroup tile: operands from LDS buffer `buf` into the wave's MFMA tiles.
+template <int WTM, int WTN>
+__device__ __forceinline__ void abt_compute(const float* As, const float* Bs, int a_row0, int b_row0, int li, int lh,
+                                            f32x16 (&acc)[WTM][WTN]) {
+    // lane (li, lh) holds k = 8*lh + j for MFMA step j: two float4 per operand tile
+    float av[WTM][8], bv[WTN][8];
+#pragma unroll
+    for (int a = 0; a < WTM; ++a) {
+        const float* p = As + (a_row0 + a * 32 + li) * kLdsLd + 8 * lh;
+        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        av[a][0] = x.x; av[a][1] = x.y; av[a][2] = x.z; av[a][3] = x.w;
+        av[a][4] = y.x; av[a][5] = y.y; av[a][6] = y.z; av[a][7] = y.w;
+    }
+#pragma unroll
+    for (int b = 0; b < WTN; ++b) {
+        const float* p = Bs + (b_row0 + b * 32 + li) * kLdsLd + 8 * lh;
+        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        bv[b][0] = x.x; bv[b][1] = x.y; bv[b][2] = x.z; bv[b][3] = x.w;
+        bv[b][4] = y.x; bv[b][5] = y.y; bv[b][6] = y.z; bv[b][7] = y.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int a = 0; a < WTM; ++a)
+#pragma unroll
+            for (int b = 0; b < WTN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+}
+
 template <int WTM, int WTN, int WVM, int WVN, int EPI>
-__global__ __launch_bounds__(256) void gemm_abt_kernel(const GemmAbt g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_abt_kernel(const GemmAbt g) {
     constexpr int TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
     static_assert(WVM * WVN == 4 && TM == 128, "4 waves, 128 rows per workgroup");
+    static_assert(TN * 4 % 256 == 0 || TN * 4 < 256, "B tile: whole float4 rounds, or a single partial one");
     __shared__ __attribute__((aligned(16))) float As[2][TM * kLdsLd];
     __shared__ __attribute__((aligned(16))) float Bs[2][TN * kLdsLd];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -37,34 +67,15 @@ __global__ __launch_bounds__(256) void gemm_abt_kernel(const GemmAbt g) {
     const int li = lane & 31, lh = lane >> 5;
     const long long m0 = (long long)blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
-    constexpr int A_F4 = TM * 4 / 256;
-    constexpr int B_F4 = (TN * 4 + 255) / 256;
-    float4 ra[A_F4], rb[B_F4];
-
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
-            ra[i] = *reinterpret_cast<const float4*>(g.A + (m0 + row) * g.lda + k0 + 4 * kq);
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
-            if (idx < TN * 4) rb[i] = *reinterpret_cast<const float4*>(g.Bt + (size_t)(n0 + row) * g.ldb + k0 + 4 * kq);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
-            *reinterpret_cast<float4*>(&As[buf][row * kLdsLd + 4 * kq]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
-            if (idx < TN * 4) *reinterpret_cast<float4*>(&Bs[buf][row * kLdsLd + 4 * kq]) = rb[i];
-        }
-    };
+    constexpr int A_F4 = TM * 4 / 256;                    // float4 per thread and k-step
+    constexpr int B_F4 = TN * 4 >= 256 ? TN * 4 / 256 : 1;
+    constexpr bool B_PARTIAL = TN * 4 < 256;              // narrow tile: only the first TN*4 threads stage B
+    const bool b_on = !B_PARTIAL || t < TN * 4;
+    // staging slots of this thread (fixed): float4 #(t + 256 i) of a [rows x 16] tile
+    const int srow = t >> 2, skq = t & 3;
+    const float* ap = g.A + (m0 + srow) * g.lda + 4 * skq;
+    const float* bp = g.Bt + (size_t)(n0 + (B_PARTIAL ? (srow % TN) : srow)) * g.ldb + 4 * skq;
+    const int soff = srow * kLdsLd + 4 * skq;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -74,39 +85,36 @@ __global__ __launch_bounds__(256) void gemm_abt_kernel(const GemmAbt g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    gload(0);
-    lstore(0);
+    // (scalars, not arrays: hipcc otherwise parks small private arrays in LDS / scratch and waits on every load)
+    static_assert(A_F4 == 2 && (B_F4 == 1 || B_F4 == 2), "staging registers below are written out by hand");
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t a1 = (size_t)64 * g.lda, b1 = (size_t)64 * g.ldb;
+    float4 ra0 = *reinterpret_cast<const float4*>(ap), ra1 = *reinterpret_cast<const float4*>(ap + a1);
+    float4 rb0 = b_on ? *reinterpret_cast<const float4*>(bp) : z4, rb1 = z4;
+    if (B_F4 == 2) rb1 = *reinterpret_cast<const float4*>(bp + b1);
+    *reinterpret_cast<float4*>(&As[0][soff]) = ra0;
+    *reinterpret_cast<float4*>(&As[0][soff + 64 * kLdsLd]) = ra1;
+    if (b_on) *reinterpret_cast<float4*>(&Bs[0][soff]) = rb0;
+    if (B_F4 == 2) *reinterpret_cast<float4*>(&Bs[0][soff + 64 * kLdsLd]) = rb1;
     __syncthreads();
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        const int buf = (k0 >> 4) & 1;
-        const bool more = k0 + 16 < g.K;
-        if (more) gload(k0 + 16);
-        // lane (li, lh) holds k = 8*lh + j for MFMA step j: two float4 per operand tile
-        float av[WTM][8], bv[WTN][8];
-#pragma unroll
-        for (int a = 0; a < WTM; ++a) {
-            const float* p = &As[buf][((wm * WTM + a) * 32 + li) * kLdsLd + 8 * lh];
-            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-            av[a][0] = x.x; av[a][1] = x.y; av[a][2] = x.z; av[a][3] = x.w;
-            av[a][4] = y.x; av[a][5] = y.y; av[a][6] = y.z; av[a][7] = y.w;
-        }
-#pragma unroll
-        for (int b = 0; b < WTN; ++b) {
-            const float* p = &Bs[buf][((wn * WTN + b) * 32 + li) * kLdsLd + 8 * lh];
-            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-            bv[b][0] = x.x; bv[b][1] = x.y; bv[b][2] = x.z; bv[b][3] = x.w;
-            bv[b][4] = y.x; bv[b][5] = y.y; bv[b][6] = y.z; bv[b][7] = y.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int a = 0; a < WTM; ++a)
-#pragma unroll
-                for (int b = 0; b < WTN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
-        if (more) lstore(buf ^ 1);
+    int buf = 0;
+    // steady state: fetch k-step s+1 into registers, multiply k-step s out of LDS, park s+1 in the other buffer
+    for (int k0 = 16; k0 < g.K; k0 += 16) {
+        ra0 = *reinterpret_cast<const float4*>(ap + k0);
+        ra1 = *reinterpret_cast<const float4*>(ap + a1 + k0);
+        if (b_on) rb0 = *reinterpret_cast<const float4*>(bp + k0);
+        if (B_F4 == 2) rb1 = *reinterpret_cast<const float4*>(bp + b1 + k0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMA block (hipcc sinks it to save VGPRs)
+        abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        *reinterpret_cast<float4*>(&As[buf ^ 1][soff]) = ra0;
+        *reinterpret_cast<float4*>(&As[buf ^ 1][soff + 64 * kLdsLd]) = ra1;
+        if (b_on) *reinterpret_cast<float4*>(&Bs[buf ^ 1][soff]) = rb0;
+        if (B_F4 == 2) *reinterpret_cast<float4*>(&Bs[buf ^ 1][soff + 64 * kLdsLd]) = rb1;
         __syncthreads();
+        buf ^= 1;
     }
+    abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -162,7 +170,31 @@ void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kAtbLd = 132;   // staged row of 128 floats + 4: lane halves (8 rows apart) fall on opposite banks
 
-__global__ __launch_bounds__(256) void gemm_atb_kernel(const GemmAtb g) {
+__device__ __forceinline__ void atb_compute(const float* As, const float* Gs, int wk, int wn, int li, int lh, int t,
+                                            bool do_colsum, f32x16 (&acc)[2][2], float& colsum) {
+    // MFMA: D[i][j] += sum_kk A[i][kk] * B[kk][j] with i = column of A (row of dW), kk = sample row, j = column of G
+    float av[2][8], bv[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* pa = As + (8 * lh + j) * kAtbLd + wk * 64 + li;
+        const float* pg = Gs + (8 * lh + j) * kAtbLd + wn * 64 + li;
+        av[0][j] = pa[0]; av[1][j] = pa[32];
+        bv[0][j] = pg[0]; bv[1][j] = pg[32];
+    }
+    if (do_colsum) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) colsum += Gs[r * kAtbLd + t];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_atb_kernel(const GemmAtb g) {
     __shared__ __attribute__((aligned(16))) float As[2][16 * kAtbLd];
     __shared__ __attribute__((aligned(16))) float Gs[2][16 * kAtbLd];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -171,26 +203,13 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(const GemmAtb g) {
     const int kb = blockIdx.x * 128, nb = blockIdx.y * 128, split = blockIdx.z;
     const long long ms = (long long)split * g.rows_per_split;
     const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
-    float4 ra[2], rg[2];
+    // staging slots of this thread: float4 #(t + 256 i), i = 0, 1, of a [16 rows x 128 cols] tile
+    const int srow = t >> 5, sc4 = t & 31;
+    const bool a_on = kb + 4 * sc4 < g.K, g_on = nb + 4 * sc4 < g.N;   // columns past K / N stage zeros
+    const float* ap = g.A + (ms + srow) * g.lda + kb + 4 * sc4;
+    const float* gp = g.G + (ms + srow) * g.ldg + nb + 4 * sc4;
+    const int soff = srow * kAtbLd + 4 * sc4;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto gload = [&](long long mrow) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = t + 256 * i, row = idx >> 5, c4 = idx & 31;
-            const int ka = kb + 4 * c4, na = nb + 4 * c4;
-            ra[i] = ka < g.K ? *reinterpret_cast<const float4*>(g.A + (mrow + row) * g.lda + ka) : zero4;
-            rg[i] = na < g.N ? *reinterpret_cast<const float4*>(g.G + (mrow + row) * g.ldg + na) : zero4;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = t + 256 * i, row = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4*>(&As[buf][row * kAtbLd + 4 * c4]) = ra[i];
-            *reinterpret_cast<float4*>(&Gs[buf][row * kAtbLd + 4 * c4]) = rg[i];
-        }
-    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -202,38 +221,35 @@ __global__ __launch_bounds__(256) void gemm_atb_kernel(const GemmAtb g) {
     float colsum = 0.f;
     const bool do_colsum = blockIdx.x == 0 && t < 128;
 
-    if (ms < me) {
-        gload(ms);
-        lstore(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (long long mrow = ms; mrow < me; mrow += 16) {
-        const bool more = mrow + 16 < me;
-        if (more) gload(mrow + 16);
-        // MFMA: D[i][j] += sum_kk A[i][kk] * B[kk][j] with i = column of A (row of dW), kk = sample row, j = column of G
-        float av[2][8], bv[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* pa = &As[buf][(8 * lh + j) * kAtbLd + wk * 64 + li];
-            const float* pg = &Gs[buf][(8 * lh + j) * kAtbLd + wn * 64 + li];
-            av[0][j] = pa[0]; av[1][j] = pa[32];
-            bv[0][j] = pg[0]; bv[1][j] = pg[32];
-        }
-        if (do_colsum) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) colsum += Gs[buf][r * kAtbLd + t];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
-        if (more) lstore(buf ^ 1);
+    if (ms < me) {      // uniform per workgroup
+        const size_t a8 = (size_t)8 * g.lda, g8 = (size_t)8 * g.ldg;
+        float4 ra0 = a_on ? *reinterpret_cast<const float4*>(ap) : zero4;
+        float4 ra1 = a_on ? *reinterpret_cast<const float4*>(ap + a8) : zero4;
+        float4 rg0 = g_on ? *reinterpret_cast<const float4*>(gp) : zero4;
+        float4 rg1 = g_on ? *reinterpret_cast<const float4*>(gp + g8) : zero4;
+        *reinterpret_cast<float4*>(&As[0][soff]) = ra0;
+        *reinterpret_cast<float4*>(&As[0][soff + 8 * kAtbLd]) = ra1;
+        *reinterpret_cast<float4*>(&Gs[0][soff]) = rg0;
+        *reinterpret_cast<float4*>(&Gs[0][soff + 8 * kAtbLd]) = rg1;
         __syncthreads();
-        buf ^= 1;
+        int buf = 0;
+        const long long steps = (me - ms) / 16;
+        for (long long st = 1; st < steps; ++st) {
+            const float* aq = ap + (size_t)st * 16 * g.lda;
+            const float* gq = gp + (size_t)st * 16 * g.ldg;
+            if (a_on) { ra0 = *reinterpret_cast<const float4*>(aq); ra1 = *reinterpret_cast<const float4*>(aq + a8); }
+            if (g_on) { rg0 = *reinterpret_cast<const float4*>(gq); rg1 = *reinterpret_cast<const float4*>(gq + g8); }
+            __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMA block
+            atb_compute(As[buf], Gs[buf], wk, wn, li, lh, t, do_colsum, acc, colsum);
+            __builtin_amdgcn_sched_barrier(0);
+            *reinterpret_cast<float4*>(&As[buf ^ 1][soff]) = ra0;
+            *reinterpret_cast<float4*>(&As[buf ^ 1][soff + 8 * kAtbLd]) = ra1;
+            *reinterpret_cast<float4*>(&Gs[buf ^ 1][soff]) = rg0;
+            *reinterpret_cast<float4*>(&Gs[buf ^ 1][soff + 8 * kAtbLd]) = rg1;
+            __syncthreads();
+            buf ^= 1;
+        }
+        atb_compute(As[buf], Gs[buf], wk, wn, li, lh, t, do_colsum, acc, colsum);
     }
 
     float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
