@@ -84,6 +84,7 @@ def main():
                     help="arithmetic of the 256-wide contractions: f16x3 = 3-pass split-fp16 MFMA with fp32 accumulate "
                          "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="1-GPU rehearsal of the per-rank work at N=<k>: render only rank 0's slab of a k-way split "
                          "(no collective); the printed value is that slab's rays/s x k (an estimate, not a result)")
@@ -178,6 +179,35 @@ def main():
                  "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel", "achieved": a32, "peak": PEAK_TFLOPS["f32"],
                               "unit": "TFLOP/s", "frac": a32 / PEAK_TFLOPS["f32"]}}
 
+    # the training step on the reference's batch, timed briefly beside the headline (N=1 only)
+    train = None
+    if world == 1 and args.rehearse_world <= 1 and not args.no_train:
+        n_tr, k_tr = 4096, 10
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        t_o = torch.zeros((n_tr, 4), device="cuda"); t_o[:, 2] = 1.0; t_o[:, 3] = 1.0
+        t_d = torch.randn((n_tr, 4), device="cuda", generator=gen) * 0.3; t_d[:, 2] = -1.0; t_d[:, 3] = 0.0
+        t_rgb = torch.rand((n_tr, 3), device="cuda", generator=gen)
+        model.compile(5e-4)
+        for i in range(2):
+            model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=i, want_metrics=False)
+        sync()
+        t2 = time.perf_counter()
+        for i in range(k_tr):
+            model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=10 + i, want_metrics=False)
+        sync()
+        e_tr = (time.perf_counter() - t2) / k_tr
+        m_tr = model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=99)
+        model.ctx.train_end()
+        tf_tr = 3 * n_tr * (SC + SF) * FLOPS_PER_ROW / e_tr / 1e12
+        train = {"metric": "train_step (NeRF.train_step: coarse+fine forward, backward incl. sampler, Adam)",
+                 "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f32",
+                 "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
+                 "loss_finite": bool(m_tr["loss"] == m_tr["loss"]),
+                 "roofline": {"bound": "mfma", "kernel": "gemm_abt / gemm_atb (layer-wise fp32 MFMA GEMMs), whole step",
+                              "achieved": tf_tr, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                              "frac": tf_tr / PEAK_TFLOPS["f32"],
+                              "flops": "3 x forward GEMM flops (forward, data gradient, weight gradient)"}}
+
     if rank == 0:
         value = total * args.steps / elapsed
         if args.rehearse_world > 1 and world == 1:
@@ -210,6 +240,8 @@ def main():
         }
         if other is not None:
             out["fp32_exact_mode"] = other
+        if train is not None:
+            out["training"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
         print(json.dumps(out), flush=True)

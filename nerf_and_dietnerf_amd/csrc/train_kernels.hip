@@ -86,34 +86,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // (scalars, not arrays: hipcc otherwise parks small private arrays in LDS / scratch and waits on every load)
-    static_assert(A_F4 == 2 && (B_F4 == 1 || B_F4 == 2), "staging registers below are written out by hand");
+    static_assert(A_F4 == 2 && (B_F4 == 1 || B_F4 == 2 || B_F4 == 4), "staging registers below are written out by hand");
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t a1 = (size_t)64 * g.lda, b1 = (size_t)64 * g.ldb;
-    float4 ra0 = *reinterpret_cast<const float4*>(ap), ra1 = *reinterpret_cast<const float4*>(ap + a1);
-    float4 rb0 = b_on ? *reinterpret_cast<const float4*>(bp) : z4, rb1 = z4;
-    if (B_F4 == 2) rb1 = *reinterpret_cast<const float4*>(bp + b1);
-    *reinterpret_cast<float4*>(&As[0][soff]) = ra0;
-    *reinterpret_cast<float4*>(&As[0][soff + 64 * kLdsLd]) = ra1;
-    if (b_on) *reinterpret_cast<float4*>(&Bs[0][soff]) = rb0;
-    if (B_F4 == 2) *reinterpret_cast<float4*>(&Bs[0][soff + 64 * kLdsLd]) = rb1;
+    float4 ra0, ra1, rb0 = z4, rb1 = z4, rb2 = z4, rb3 = z4;
+#define ABT_FETCH(K0)                                                                      \
+    ra0 = *reinterpret_cast<const float4*>(ap + (K0));                                     \
+    ra1 = *reinterpret_cast<const float4*>(ap + a1 + (K0));                                \
+    if (b_on) rb0 = *reinterpret_cast<const float4*>(bp + (K0));                           \
+    if (B_F4 >= 2) rb1 = *reinterpret_cast<const float4*>(bp + b1 + (K0));                 \
+    if (B_F4 == 4) {                                                                       \
+        rb2 = *reinterpret_cast<const float4*>(bp + 2 * b1 + (K0));                        \
+        rb3 = *reinterpret_cast<const float4*>(bp + 3 * b1 + (K0));                        \
+    }
+#define ABT_PARK(BUF)                                                                      \
+    *reinterpret_cast<float4*>(&As[BUF][soff]) = ra0;                                      \
+    *reinterpret_cast<float4*>(&As[BUF][soff + 64 * kLdsLd]) = ra1;                        \
+    if (b_on) *reinterpret_cast<float4*>(&Bs[BUF][soff]) = rb0;                            \
+    if (B_F4 >= 2) *reinterpret_cast<float4*>(&Bs[BUF][soff + 64 * kLdsLd]) = rb1;         \
+    if (B_F4 == 4) {                                                                       \
+        *reinterpret_cast<float4*>(&Bs[BUF][soff + 128 * kLdsLd]) = rb2;                   \
+        *reinterpret_cast<float4*>(&Bs[BUF][soff + 192 * kLdsLd]) = rb3;                   \
+    }
+    ABT_FETCH(0)
+    ABT_PARK(0)
     __syncthreads();
     int buf = 0;
     // steady state: fetch k-step s+1 into registers, multiply k-step s out of LDS, park s+1 in the other buffer
     for (int k0 = 16; k0 < g.K; k0 += 16) {
-        ra0 = *reinterpret_cast<const float4*>(ap + k0);
-        ra1 = *reinterpret_cast<const float4*>(ap + a1 + k0);
-        if (b_on) rb0 = *reinterpret_cast<const float4*>(bp + k0);
-        if (B_F4 == 2) rb1 = *reinterpret_cast<const float4*>(bp + b1 + k0);
+        ABT_FETCH(k0)
         __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMA block (hipcc sinks it to save VGPRs)
         abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
         __builtin_amdgcn_sched_barrier(0);
-        *reinterpret_cast<float4*>(&As[buf ^ 1][soff]) = ra0;
-        *reinterpret_cast<float4*>(&As[buf ^ 1][soff + 64 * kLdsLd]) = ra1;
-        if (b_on) *reinterpret_cast<float4*>(&Bs[buf ^ 1][soff]) = rb0;
-        if (B_F4 == 2) *reinterpret_cast<float4*>(&Bs[buf ^ 1][soff + 64 * kLdsLd]) = rb1;
+        ABT_PARK(buf ^ 1)
         __syncthreads();
         buf ^= 1;
     }
+#undef ABT_FETCH
+#undef ABT_PARK
     abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -150,7 +160,7 @@ static void launch_abt_epi(bool narrow, const GemmAbt& g, hipStream_t s) {
     if (narrow)
         hipLaunchKernelGGL((gemm_abt_kernel<1, 1, 4, 1, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 32)),
                            dim3(256), 0, s, g);
-    else
+    else     // (a 128x256 tile -- A read once, occupancy 2 -- measured 9 % slower than two 128x128 tiles at occupancy 3)
         hipLaunchKernelGGL((gemm_abt_kernel<2, 2, 2, 2, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 128)),
                            dim3(256), 0, s, g);
 }

@@ -10,8 +10,11 @@ for k in 2 4 8; do timeout -k 10 200 python bench.py --rehearse-world $k --steps
 if [ -f nerf_and_dietnerf_amd/lib/libnerf_st.so ]; then NERF_MI355_LIB=$PWD/nerf_and_dietnerf_amd/lib/libnerf_st.so timeout -k 10 100 python tools/stamps.py f16x3 2>&1 | tail -12; fi
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_r1f -o f16 --output-format csv -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /root/repo/gpurun_out/prof_r1f.log 2>&1; echo "prof rc $?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_train -o train --output-format csv -- python3 /root/repo/tools/train_bench.py 5 > /root/repo/gpurun_out/prof_train.log 2>&1; echo "prof train rc $?"; tail -1 /root/repo/gpurun_out/prof_train.log
+if [ -z "$SKIP_PMC" ]; then
 for mode in f16x3 fp32; do
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /root/repo/gpurun_out/pmc_${mode}a -o a --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision $mode > /root/repo/gpurun_out/pmc_${mode}a.log 2>&1; echo "pmcA $mode rc $?"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_${mode}b -o b --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision $mode > /root/repo/gpurun_out/pmc_${mode}b.log 2>&1; echo "pmcB $mode rc $?"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_${mode}c -o c --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision $mode > /root/repo/gpurun_out/pmc_${mode}c.log 2>&1; echo "pmcC $mode rc $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /root/repo/gpurun_out/pmc_${mode}a -o a --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --precision $mode > /root/repo/gpurun_out/pmc_${mode}a.log 2>&1; echo "pmcA $mode rc $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_${mode}b -o b --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --precision $mode > /root/repo/gpurun_out/pmc_${mode}b.log 2>&1; echo "pmcB $mode rc $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_${mode}c -o c --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --precision $mode > /root/repo/gpurun_out/pmc_${mode}c.log 2>&1; echo "pmcC $mode rc $?"
 done
+fi
