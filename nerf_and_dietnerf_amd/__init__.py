@@ -12,7 +12,8 @@ from .render import (Context, NeRF, NetHandle, default_context, get_rays_directi
                      get_z_vals_from_prob_dist_func, get_z_values, model_predict, positional_encoding_for_views,
                      positional_encoding_for_xyz, ray_marching, render_rays, split_to_batches)
 from .keras_h5 import load_nerf_checkpoint, read_keras_weights
-from .sharding import gather_slabs, ray_slab, render_image_sharded
+from .sharding import allreduce_mean, dist_world, gather_slabs, ray_slab, render_image_sharded
+from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
 from .video import (get_l_to_r_c2w_matrices, get_sphere_matrices, get_sphere_matrix, histogram_equalize_depth,
                     render_video)
 from .weights import blob_size, glorot_blob, layer_shapes

@@ -196,3 +196,53 @@ def test_nerf_mirror_train_step_and_full_batch_timing(oracle, golden_ckpt, capsy
     with capsys.disabled():
         print(f"\n[train] 4096 rays x (64 coarse + 128 fine): {dt * 1e3:.1f} ms/step (host arrays in, metrics out)")
     m.ctx.close()
+
+
+def test_fit_distils_the_shipped_checkpoint(oracle, golden_ckpt, capsys):
+    """End to end: prepare_ds + fit on the GPU.  Teacher = the reference's shipped epoch-95 model rendered by the
+    render path on a ring of cameras (config-1 geometry: 50 px class images, its near/far/fov); student = fresh
+    Glorot networks trained with NeRF.train_step.  The held-out view must improve by > 6 dB and pass 20 dB."""
+    import torch
+    import nerf_and_dietnerf_amd as N
+    near, far, fov = float(golden_ckpt["near"]), float(golden_ckpt["far"]), float(golden_ckpt["fov"])
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
+               "n_rays_in_batch_train": 2048, "n_rays_in_batch_render": 4096}
+    ren_cfg = {"n_render_samples_coarse": 32, "n_render_samples_fine": 64}
+    teacher = N.NeRF(net_cfg, ren_cfg, near, far, precision="f16x3")
+    teacher.set_weights(golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
+    base = np.asarray(golden_ckpt["c2w_train"], np.float32)
+    hw = 40
+
+    def pose(deg):                                   # rotate the dataset's own camera about the world y axis
+        a = np.deg2rad(deg)
+        r = np.eye(4, dtype=np.float32)
+        r[0, 0], r[0, 2], r[2, 0], r[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+        return (r @ base).astype(np.float32)
+
+    train_poses = [pose(d) for d in np.linspace(-24, 24, 13)]
+    test_pose = pose(10.0)
+    imgs = [teacher.render_image(p, fov, hw, hw, seed=i, device_out=True, rgb_only=True)[0].clamp(0, 1)
+            for i, p in enumerate(train_poses)]
+    target = teacher.render_image(test_pose, fov, hw, hw, seed=99, device_out=True, rgb_only=True)[0].clamp(0, 1)
+    teacher.ctx.close()
+
+    student = N.NeRF(net_cfg, ren_cfg, near, far)
+    student.set_weights(N.glorot_blob(11), N.glorot_blob(12))
+    student.compile(5e-4)
+
+    def psnr():
+        out = student.render_image(test_pose, fov, hw, hw, seed=5, device_out=True, rgb_only=True)[0]
+        return float(-10 * torch.log10(torch.mean((out - target) ** 2)))
+
+    before = psnr()
+    ds = N.prepare_ds(net_cfg["n_rays_in_batch_train"], train_poses, imgs, fov, student.ctx, seed=3)
+    assert ds.n_rays == 13 * hw * hw and len(ds) == -(-ds.n_rays // 2048)
+    hist = N.fit(student, ds, epochs=30)
+    after = psnr()
+    with capsys.disabled():
+        print(f"\n[fit] {30 * len(ds)} steps: held-out PSNR {before:.2f} -> {after:.2f} dB; epoch-mean loss "
+              f"{hist[0]['loss']:.4f} -> {hist[-1]['loss']:.4f}")
+    assert hist[-1]["loss"] < 0.5 * hist[0]["loss"]
+    assert after > before + 6.0 and after > 20.0
+    student.ctx.close()
