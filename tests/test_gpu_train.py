@@ -246,3 +246,53 @@ def test_fit_distils_the_shipped_checkpoint(oracle, golden_ckpt, capsys):
     assert hist[-1]["loss"] < 0.5 * hist[0]["loss"]
     assert after > before + 6.0 and after > 20.0
     student.ctx.close()
+
+
+def _dp_rank(rank, world, port, prob, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # 2 ranks share the one GPU of this box
+    try:
+        import nerf_and_dietnerf_amd as N
+        ctx = N.Context(near=prob["near"], far=prob["far"])
+        ctx.load_weights(0, prob["bc"])
+        ctx.load_weights(1, prob["bf"])
+        ctx.train_begin(5e-4)
+        n = prob["o"].shape[0] // world
+        sl = slice(rank * n, (rank + 1) * n)
+        m, gc, gf = ctx.train_gradients(prob["o"][sl], prob["d"][sl], prob["tgt"][sl], prob["sc"], prob["sf"],
+                                        prob["u_c"][sl], prob["u_f"][sl])
+        gc, gf = N.allreduce_mean(gc), N.allreduce_mean(gf)
+        ctx.train_apply(gc, gf)
+        q.put((rank, gc, gf, ctx.get_weights(0)))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_full_batch(oracle, golden_ckpt):
+    """Two ranks (gloo, sharing this box's GPU), half the batch each, one all-reduce per gradient blob: the
+    averaged gradients equal the single-process full-batch gradients (MSE is a mean over rays) and both ranks
+    end the step with identical weights."""
+    import socket
+    import torch.multiprocessing as mp
+    p = _problem(oracle, golden_ckpt, n=64, sc=16, sf=24, seed=4)
+    ctx = _ctx(p)
+    ctx.train_begin(5e-4)
+    _, gc_full, gf_full = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    ctx.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_dp_rank, args=(r, 2, port, p, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, gc, gf, w in res:
+        assert _relerr(gc, gc_full) <= 1e-5 and _relerr(gf, gf_full) <= 1e-5, rank
+    np.testing.assert_array_equal(res[0][3], res[1][3])
