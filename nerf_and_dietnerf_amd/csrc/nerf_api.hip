@@ -58,9 +58,15 @@ int enter(nerf_ctx* c) {
 
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob) {
     HIP_OK(hipSetDevice(c->cfg.device));
+    NetWeights& n = c->net[which];
+    if (c->cfg.n_angles == 0) {      // xyz-only network: served by the layer-wise path (train_api.hip), nothing to pack
+        const size_t nf0 = nerf_blob_size(&c->cfg);
+        if (n.host_blob.data() != blob) n.host_blob.assign(blob, blob + nf0);
+        n.loaded = true;
+        return 0;
+    }
     std::vector<float> st(kStreamBytes / 4), cs(kConstFloats);
     pack_weights_fp32(blob, c->cfg.n_angles, st.data(), cs.data());
-    NetWeights& n = c->net[which];
     if (!n.stream) HIP_OK(hipMalloc((void**)&n.stream, kStreamBytes));
     if (!n.cst) HIP_OK(hipMalloc((void**)&n.cst, kConstBytes));
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -86,11 +92,10 @@ namespace {
 
 int check_cfg(const nerf_config* cfg) {
     if (!cfg) return fail("nerf_config is NULL");
-    if (cfg->n_angles != 2 && cfg->n_angles != 1) {
-        if (cfg->n_angles == 0)
-            return fail("n_angles_for_model=0 (the xyz-only network, src/NeRF.py:248-288) is not built yet");
-        return fail("n_angles_for_model should be 1 or 2.");   // message of src/UtilsCV.py:138
-    }
+    if (cfg->n_angles != 2 && cfg->n_angles != 1 && cfg->n_angles != 0)
+        return fail("n_angles_for_model should be 1 or 2.");   // message of src/UtilsCV.py:138 (0 = xyz-only network)
+    if (cfg->n_angles == 0 && cfg->precision != NERF_PRECISION_FP32)
+        return fail("the xyz-only network (n_angles_for_model=0) runs on the layer-wise fp32 path: use NERF_PRECISION_FP32");
     if (cfg->n_pos_enc_xyz != kLx || cfg->n_pos_enc_dir != kLd || cfg->hidden_dim != kHidden ||
         cfg->last_hidden_dim != kLast)
         return fail("fused kernel is specialised for Lx=%d Ld=%d hidden=%d last=%d (got %d %d %d %d)", kLx, kLd,
@@ -105,6 +110,11 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
             int S, int mode) {
     if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
     if (int r = train_flush_weights(c, which)) return r;   // re-pack the operand streams after optimizer steps
+    if (c->cfg.n_angles == 0) {
+        if (mode == 1 && !in_a) return fail("NULL argument");
+        c->timed_rows += c->timing ? M : 0;
+        return layerwise_forward(c, which, in_a, in_b, z, raw, M, S, mode);
+    }
     const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3;
     MlpArgs a;
     a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
@@ -215,6 +225,9 @@ const char* nerf_last_error(void) { return g_err.c_str(); }
 
 size_t nerf_blob_size(const nerf_config* cfg) {
     if (check_cfg(cfg)) return 0;
+    if (cfg->n_angles == 0)   // get_network_only_xyz, src/NeRF.py:248-288: 12 Dense layers
+        return 33 * 256 + 256 + 3 * (256 * 256 + 256) + 289 * 256 + 256 + 3 * (256 * 256 + 256) + (256 * 256 + 256) +
+               256 * 128 + 128 + 128 * 3 + 3 + 256 + 1;
     const size_t kd = 256 + 8 * (size_t)(cfg->n_angles + 1);   // [hidden, dir_enc]: 280 or 272
     return 33 * 256 + 256 + 3 * (256 * 256 + 256) + 289 * 256 + 256 + 3 * (256 * 256 + 256) + kd * 128 + 128 +
            128 * 3 + 3 + kd + 1;
@@ -297,6 +310,8 @@ int nerf_ctx_set_precision(nerf_ctx* c, int precision) {
     if (!c) return fail("ctx is NULL");
     if (precision != NERF_PRECISION_FP32 && precision != NERF_PRECISION_F16X3)
         return fail("unknown precision %d", precision);
+    if (c->cfg.n_angles == 0 && precision != NERF_PRECISION_FP32)
+        return fail("the xyz-only network (n_angles_for_model=0) runs on the layer-wise fp32 path: use NERF_PRECISION_FP32");
     HIP_OK(hipStreamSynchronize(c->stream));
     c->cfg.precision = precision;
     return 0;
@@ -402,16 +417,18 @@ int nerf_positional_encoding(nerf_ctx* c, const float* x, int64_t M, int32_t n_e
 int nerf_model_predict(nerf_ctx* c, int which, const float* xyz, const float* view_dirs, int64_t M, float* raw,
                        int mem) {
     ENTER(c);
-    if (!c || !xyz || !view_dirs || !raw) return fail("NULL argument");
+    // view_dirs may be NULL for the xyz-only network (model_predict(..., view_dirs=None), UtilsNRF.py:229-234)
+    if (!c || !xyz || !raw || (!view_dirs && c->cfg.n_angles != 0)) return fail("NULL argument");
     if (which != 0 && which != 1) return fail("which must be 0 (coarse) or 1 (fine)");
     if (M < 0) return fail("bad M");
     const float *dx = xyz, *dv = view_dirs;
     float* dr = raw;
     if (mem == NERF_MEM_HOST) {
         if (int r = h2d(c, c->b_in0, xyz, (size_t)M * 12)) return r;
-        if (int r = h2d(c, c->b_in1, view_dirs, (size_t)M * 12)) return r;
+        if (view_dirs)
+            if (int r = h2d(c, c->b_in1, view_dirs, (size_t)M * 12)) return r;
         if (int r = ensure(c, c->b_raw, (size_t)M * 16)) return r;
-        dx = (const float*)c->b_in0.p; dv = (const float*)c->b_in1.p; dr = (float*)c->b_raw.p;
+        dx = (const float*)c->b_in0.p; dv = view_dirs ? (const float*)c->b_in1.p : nullptr; dr = (float*)c->b_raw.p;
     }
     if (int r = run_mlp(c, which, dx, dv, nullptr, dr, M, 1, 1)) return r;
     if (mem == NERF_MEM_HOST) {

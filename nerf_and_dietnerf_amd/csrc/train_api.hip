@@ -24,46 +24,57 @@ struct TNet {
     bool present = false;
     bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
-    TLayer L[11];
+    int n_layers = 11;             // 11: xyz + view-direction network; 12: xyz-only network (n_angles_for_model = 0)
+    TLayer L[12];
 };
 
 struct TPass {                      // activations of one pass, kept from forward to backward
-    DevBuf C4, C8, H1, H2, H3, H5, H6, H7, H9, raw, T, w, rgb, z;
+    DevBuf C4, C8, H1, H2, H3, H5, H6, H7, H8b, H9, raw, T, w, rgb, z;   // H8b: xyz-only network's extra layer
 };
 
 struct TrainState {
     nerf_train_config cfg;
+    bool training = false;          // false: created only to serve the layer-wise forward of the xyz-only network
     long long step = 0;
     size_t nblob = 0;
     TNet net[2];
     TPass pass[2];
     DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal;
+    TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
 }  // namespace nerf
 
 namespace {
 
-void layer_table(const nerf_config& cfg, TLayer L[11]) {
+int layer_table(const nerf_config& cfg, TLayer L[12]) {
     const int kd = 8 * (cfg.n_angles + 1);
-    const int shape[11][5] = {
+    // {K_real, N_real, Kp, Np, rowmap}
+    const int with_dirs[11][5] = {
         {33, 256, kXyzPad, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
         {289, 256, kLdC4, 256, 1},  {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
         {256 + kd, 128, kLdC8, 128, 0}, {128, 3, 128, 32, 0}, {256 + kd, 1, kLdC8, 32, 0}};
+    // get_network_only_xyz (src/NeRF.py:248-288): ... h8 -> dense 256 -> dense 128 -> rgb; sigma from h8
+    const int xyz_only[12][5] = {
+        {33, 256, kXyzPad, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
+        {289, 256, kLdC4, 256, 1},  {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0}, {256, 256, 256, 256, 0},
+        {256, 256, 256, 256, 0}, {256, 128, 256, 128, 0}, {128, 3, 128, 32, 0}, {256, 1, 256, 32, 0}};
+    const int n = cfg.n_angles == 0 ? 12 : 11;
     size_t off = 0;
-    for (int l = 0; l < 11; ++l) {
-        L[l].K_real = shape[l][0]; L[l].N_real = shape[l][1]; L[l].Kp = shape[l][2]; L[l].Np = shape[l][3];
-        L[l].rowmap = shape[l][4];
+    for (int l = 0; l < n; ++l) {
+        const int* sh = cfg.n_angles == 0 ? xyz_only[l] : with_dirs[l];
+        L[l].K_real = sh[0]; L[l].N_real = sh[1]; L[l].Kp = sh[2]; L[l].Np = sh[3]; L[l].rowmap = sh[4];
         L[l].w_off = off; off += (size_t)L[l].K_real * L[l].N_real;
         L[l].b_off = off; off += L[l].N_real;
         L[l].W = L[l].WT = L[l].bias = nullptr;
     }
+    return n;
 }
 
 void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 int relayout_net(nerf_ctx* c, TNet& n) {
-    for (int l = 0; l < 11; ++l) {
+    for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
         a.w = n.blob + L.w_off; a.b = n.blob + L.b_off;
@@ -75,22 +86,29 @@ int relayout_net(nerf_ctx* c, TNet& n) {
     return 0;
 }
 
-int init_net(nerf_ctx* c, TrainState* t, int which) {
-    TNet& n = t->net[which];
-    layer_table(c->cfg, n.L);
+int alloc_optimizer(nerf_ctx* c, TrainState* t, TNet& n) {
     const size_t nb = t->nblob * sizeof(float);
-    HIP_OK(hipMalloc((void**)&n.blob, nb));
-    HIP_OK(hipMalloc((void**)&n.grad, nb));
-    HIP_OK(hipMalloc((void**)&n.m, nb));
-    HIP_OK(hipMalloc((void**)&n.v, nb));
+    if (!n.grad) HIP_OK(hipMalloc((void**)&n.grad, nb));
+    if (!n.m) HIP_OK(hipMalloc((void**)&n.m, nb));
+    if (!n.v) HIP_OK(hipMalloc((void**)&n.v, nb));
     HIP_OK(hipMemsetAsync(n.m, 0, nb, c->stream));
     HIP_OK(hipMemsetAsync(n.v, 0, nb, c->stream));
     HIP_OK(hipMemsetAsync(n.grad, 0, nb, c->stream));
+    return 0;
+}
+
+int init_net(nerf_ctx* c, TrainState* t, int which) {
+    TNet& n = t->net[which];
+    n.n_layers = layer_table(c->cfg, n.L);
+    const size_t nb = t->nblob * sizeof(float);
+    HIP_OK(hipMalloc((void**)&n.blob, nb));
+    if (t->training)
+        if (int r = alloc_optimizer(c, t, n)) return r;
     size_t mats = 0;
-    for (int l = 0; l < 11; ++l) mats += 2 * (size_t)n.L[l].Kp * n.L[l].Np + n.L[l].Np;
+    for (int l = 0; l < n.n_layers; ++l) mats += 2 * (size_t)n.L[l].Kp * n.L[l].Np + n.L[l].Np;
     HIP_OK(hipMalloc((void**)&n.mats, mats * sizeof(float)));
     float* p = n.mats;
-    for (int l = 0; l < 11; ++l) {
+    for (int l = 0; l < n.n_layers; ++l) {
         TLayer& L = n.L[l];
         L.W = p; p += (size_t)L.Kp * L.Np;
         L.WT = p; p += (size_t)L.Kp * L.Np;
@@ -113,6 +131,7 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     DevBuf* hs[] = {&p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7};
     for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * 256 * f);
     r |= ensure(c, p.H9, d.Mp * 128 * f);
+    if (c->cfg.n_angles == 0) r |= ensure(c, p.H8b, d.Mp * 256 * f);
     r |= ensure(c, p.raw, d.Mp * 4 * f);
     r |= ensure(c, p.T, d.M * f);
     r |= ensure(c, p.w, d.M * f);
@@ -130,24 +149,38 @@ void fwd_layer(nerf_ctx* c, const TLayer& L, const float* A, int lda, float* Out
     launch_gemm_abt(linear_head ? EPI_FWD_LINEAR : EPI_FWD_LEAKY, linear_head, g, c->stream);
 }
 
+// the Dense stack over Mp encoded rows (C4 / C8 hold the encodings) -> raw_out (Mp x 4)
+void forward_layers(nerf_ctx* c, TNet& n, TPass& p, long long Mp, float* raw) {
+    float *C4 = (float*)p.C4.p, *C8 = (float*)p.C8.p;
+    float *H1 = (float*)p.H1.p, *H2 = (float*)p.H2.p, *H3 = (float*)p.H3.p, *H5 = (float*)p.H5.p,
+          *H6 = (float*)p.H6.p, *H7 = (float*)p.H7.p, *H9 = (float*)p.H9.p;
+    fwd_layer(c, n.L[0], C4 + 256, kLdC4, H1, 256, Mp);
+    fwd_layer(c, n.L[1], H1, 256, H2, 256, Mp);
+    fwd_layer(c, n.L[2], H2, 256, H3, 256, Mp);
+    fwd_layer(c, n.L[3], H3, 256, C4, kLdC4, Mp);          // h4 lands next to xyz_enc: the skip concat
+    fwd_layer(c, n.L[4], C4, kLdC4, H5, 256, Mp);
+    fwd_layer(c, n.L[5], H5, 256, H6, 256, Mp);
+    fwd_layer(c, n.L[6], H6, 256, H7, 256, Mp);
+    fwd_layer(c, n.L[7], H7, 256, C8, kLdC8, Mp);          // h8 lands next to dir_enc
+    if (n.n_layers == 11) {
+        fwd_layer(c, n.L[8], C8, kLdC8, H9, 128, Mp);
+        fwd_layer(c, n.L[9], H9, 128, raw, 4, Mp, true, 3);          // rgb head   -> raw[:, 0:3]
+        fwd_layer(c, n.L[10], C8, kLdC8, raw + 3, 4, Mp, true, 1);   // sigma head -> raw[:, 3]
+    } else {                                                // xyz-only: h8 -> 256 -> 128 -> rgb; sigma from h8
+        float* H8b = (float*)p.H8b.p;
+        fwd_layer(c, n.L[8], C8, kLdC8, H8b, 256, Mp);
+        fwd_layer(c, n.L[9], H8b, 256, H9, 128, Mp);
+        fwd_layer(c, n.L[10], H9, 128, raw, 4, Mp, true, 3);
+        fwd_layer(c, n.L[11], C8, kLdC8, raw + 3, 4, Mp, true, 1);
+    }
+}
+
 int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const float* o, const float* dirs) {
     TNet& n = t->net[which];
     TPass& p = t->pass[which];
-    float *C4 = (float*)p.C4.p, *C8 = (float*)p.C8.p, *raw = (float*)p.raw.p, *z = (float*)p.z.p;
-    float *H1 = (float*)p.H1.p, *H2 = (float*)p.H2.p, *H3 = (float*)p.H3.p, *H5 = (float*)p.H5.p,
-          *H6 = (float*)p.H6.p, *H7 = (float*)p.H7.p, *H9 = (float*)p.H9.p;
-    launch_train_encode(o, dirs, z, d.N, d.S, d.Mp, c->cfg.n_angles, C4, C8, c->stream);
-    fwd_layer(c, n.L[0], C4 + 256, kLdC4, H1, 256, d.Mp);
-    fwd_layer(c, n.L[1], H1, 256, H2, 256, d.Mp);
-    fwd_layer(c, n.L[2], H2, 256, H3, 256, d.Mp);
-    fwd_layer(c, n.L[3], H3, 256, C4, kLdC4, d.Mp);          // h4 lands next to xyz_enc: the skip concat
-    fwd_layer(c, n.L[4], C4, kLdC4, H5, 256, d.Mp);
-    fwd_layer(c, n.L[5], H5, 256, H6, 256, d.Mp);
-    fwd_layer(c, n.L[6], H6, 256, H7, 256, d.Mp);
-    fwd_layer(c, n.L[7], H7, 256, C8, kLdC8, d.Mp);          // h8 lands next to dir_enc
-    fwd_layer(c, n.L[8], C8, kLdC8, H9, 128, d.Mp);
-    fwd_layer(c, n.L[9], H9, 128, raw, 4, d.Mp, true, 3);    // rgb head   -> raw[:, 0:3]
-    fwd_layer(c, n.L[10], C8, kLdC8, raw + 3, 4, d.Mp, true, 1);   // sigma head -> raw[:, 3]
+    float *raw = (float*)p.raw.p, *z = (float*)p.z.p;
+    launch_train_encode(o, dirs, z, 0, d.M, d.S, d.Mp, c->cfg.n_angles, 0, (float*)p.C4.p, (float*)p.C8.p, c->stream);
+    forward_layers(c, n, p, d.Mp, raw);
     launch_composite(raw, z, d.N, d.S, (float*)p.rgb.p, (float*)p.w.p, (float*)p.T.p, nullptr, nullptr, nullptr,
                      c->stream);
     HIP_OK(hipGetLastError());
@@ -201,12 +234,24 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     float *Ga = (float*)t->Ga.p, *Gb = (float*)t->Gb.p, *G9 = (float*)t->G9.p, *Graw = (float*)t->Graw.p,
           *dA0 = (float*)t->dA0.p;
     const bool dx = d_z != nullptr;
-    wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
-    wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-    launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
-    wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp);
-    // dL/dh8 = G9 . W8[hidden rows]^T + Graw[:,3] * W10[hidden rows]   (WT10 row 0 = the sigma head's column)
-    dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[10].WT);
+    if (n.n_layers == 11) {
+        wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
+        wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
+        launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
+        wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp);
+        // dL/dh8 = G9 . W8[hidden rows]^T + Graw[:,3] * W10[hidden rows]   (WT10 row 0 = the sigma head's column)
+        dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[10].WT);
+    } else {
+        float* H8b = (float*)p.H8b.p;
+        wgrad(c, t, n, 10, H9, 128, Graw, 4, 4, 0, Mp);
+        wgrad(c, t, n, 11, C8, kLdC8, Graw, 4, 4, 3, Mp);
+        launch_head_bwd(Graw, n.L[10].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
+        wgrad(c, t, n, 9, H8b, 256, G9, 128, 128, 0, Mp);
+        dgrad(c, G9, 128, 128, n.L[9].W, 128, 256, H8b, 256, Gb, 256, Mp);            // -> pre-activation grad of h8b
+        wgrad(c, t, n, 8, C8, kLdC8, Gb, 256, 256, 0, Mp);
+        // dL/dh8 = Gb . W8^T + Graw[:,3] * W11   (WT11 row 0 = the sigma head's column)
+        dgrad(c, Gb, 256, 256, n.L[8].W, 256, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[11].WT);
+    }
     wgrad(c, t, n, 7, H7, 256, Ga, 256, 256, 0, Mp);
     dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp);
     wgrad(c, t, n, 6, H6, 256, Gb, 256, 256, 0, Mp);
@@ -242,7 +287,7 @@ int stage_in(nerf_ctx* c, DevBuf& b, const float* src, size_t bytes, int mem, co
 int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const float* target, int64_t N, int Sc,
                    int Sf, const float* u_c, const float* u_f, uint64_t seed, int mem) {
     TrainState* t = c->train;
-    if (!t) return fail("nerf_train_begin has not been called");
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
     if (!rays_o || !rays_d || !target) return fail("NULL argument");
     if (N <= 0) return fail("need at least one ray (got %lld)", (long long)N);
     if (Sc < 1 || Sc > 1024) return fail("bad coarse sample count %d", Sc);
@@ -349,8 +394,11 @@ void train_free(nerf_ctx* c) {
         if (n.v) (void)hipFree(n.v);
         if (n.mats) (void)hipFree(n.mats);
     }
-    for (auto& p : t->pass) {
-        DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H9, &p.raw, &p.T, &p.w, &p.rgb, &p.z};
+    TPass* passes[] = {&t->pass[0], &t->pass[1], &t->infer};
+    for (TPass* pp : passes) {
+        TPass& p = *pp;
+        DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
+                        &p.rgb, &p.z};
         for (DevBuf* b : bs) free_buf(*b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
@@ -362,6 +410,13 @@ void train_free(nerf_ctx* c) {
 
 int train_on_load(nerf_ctx* c, int which) {
     TrainState* t = c->train;
+    if (!t && c->cfg.n_angles == 0) {
+        // the xyz-only network renders through the layer-wise GEMM path: keep its padded matrices resident
+        t = new TrainState();
+        t->training = false;
+        t->nblob = nerf_blob_size(&c->cfg);
+        c->train = t;
+    }
     if (!t) return 0;
     TNet& n = t->net[which];
     if (!n.present) return init_net(c, t, which);
@@ -371,9 +426,40 @@ int train_on_load(nerf_ctx* c, int which) {
     return relayout_net(c, n);
 }
 
+// Render-path MLP for the xyz-only network (no fused kernel is built for it): encode + Dense stack layer by
+// layer on the fp32 MFMA GEMMs, in chunks of 128 Ki sample rows (1.2 GB of activations per chunk).
+int layerwise_forward(nerf_ctx* c, int which, const float* in_a, const float* in_b, const float* z, float* raw,
+                      long long M, int S, int mode) {
+    TrainState* t = c->train;
+    if (!t || !t->net[which].present) return fail("network %d has no weights loaded", which);
+    constexpr long long kChunk = 1 << 17;
+    const long long cap = M < kChunk ? (M + 127) / 128 * 128 : kChunk;
+    PassDims d{0, S, cap, cap};
+    TPass& p = t->infer;
+    if (int r = ensure_pass(c, p, d)) return r;
+    for (long long row0 = 0; row0 < M; row0 += kChunk) {
+        const long long rows = M - row0 < kChunk ? M - row0 : kChunk;
+        const long long Mp = (rows + 127) / 128 * 128;
+        launch_train_encode(in_a, in_b, z, row0, rows, S, Mp, c->cfg.n_angles, mode, (float*)p.C4.p, (float*)p.C8.p,
+                            c->stream);
+        if (Mp == rows) {
+            forward_layers(c, t->net[which], p, Mp, raw + row0 * 4);
+        } else {   // the padded tail rows must not be written past the caller's (M,4) buffer
+            forward_layers(c, t->net[which], p, Mp, (float*)p.raw.p);
+            HIP_OK(hipMemcpyAsync(raw + row0 * 4, p.raw.p, rows * 4 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int train_flush_weights(nerf_ctx* c, int which) {
     TrainState* t = c->train;
     if (!t || !t->net[which].present || !t->net[which].render_dirty) return 0;
+    if (c->cfg.n_angles == 0) {      // the layer-wise path reads the trainer's own matrices: nothing to re-pack
+        t->net[which].render_dirty = false;
+        return 0;
+    }
     NetWeights& nw = c->net[which];
     HIP_OK(hipMemcpyAsync(nw.host_blob.data(), t->net[which].blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost,
                           c->stream));
@@ -391,14 +477,22 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     if (!cfg) return fail("nerf_train_config is NULL");
     if (!(cfg->learning_rate > 0.f)) return fail("learning_rate must be positive");
     if (!c->net[0].loaded) return fail("load the coarse network's weights before nerf_train_begin");
-    if (c->train) train_free(c);
-    TrainState* t = new TrainState();
+    if (c->train && c->train->training) train_free(c);
+    TrainState* t = c->train;           // an inference-only state (xyz-only network) is promoted in place
+    if (!t) {
+        t = new TrainState();
+        t->nblob = nerf_blob_size(&c->cfg);
+        c->train = t;
+    }
     t->cfg = *cfg;
-    t->nblob = nerf_blob_size(&c->cfg);
-    c->train = t;
-    for (int w = 0; w < 2; ++w)
-        if (c->net[w].loaded)
+    t->training = true;
+    t->step = 0;
+    for (int w = 0; w < 2; ++w) {
+        if (!c->net[w].loaded) continue;
+        if (!t->net[w].present) {
             if (int r = init_net(c, t, w)) { train_free(c); return r; }
+        } else if (int r = alloc_optimizer(c, t, t->net[w])) { train_free(c); return r; }
+    }
     return 0;
 }
 
@@ -407,12 +501,21 @@ int nerf_train_end(nerf_ctx* c) {
     for (int w = 0; w < 2; ++w)
         if (int r = train_flush_weights(c, w)) return r;
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (c->cfg.n_angles == 0 && c->train) {
+        // the render path of the xyz-only network keeps using the (now trained) matrices; sync the host copy
+        for (int w = 0; w < 2; ++w)
+            if (c->train->net[w].present)
+                HIP_OK(hipMemcpy(c->net[w].host_blob.data(), c->train->net[w].blob, c->train->nblob * sizeof(float),
+                                 hipMemcpyDeviceToHost));
+        c->train->training = false;
+        return 0;
+    }
     train_free(c);
     return 0;
 }
 
 int nerf_train_set_learning_rate(nerf_ctx* c, float lr) {
-    if (!c || !c->train) return fail("nerf_train_begin has not been called");
+    if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
     if (!(lr > 0.f)) return fail("learning_rate must be positive");
     c->train->cfg.learning_rate = lr;
     return 0;
@@ -438,7 +541,7 @@ int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_
 int nerf_train_apply(nerf_ctx* c, const float* grad_coarse, const float* grad_fine, int mem) {
     ENTER(c);
     TrainState* t = c->train;
-    if (!t) return fail("nerf_train_begin has not been called");
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
     const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (grad_coarse) HIP_OK(hipMemcpyAsync(t->net[0].grad, grad_coarse, t->nblob * sizeof(float), kind, c->stream));
     if (grad_fine) {

@@ -355,8 +355,9 @@ void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float l
 //   src/UtilsNeuralRadianceField.py:52-85.  Rows >= N*S (padding to 128) get zeros.
 // ------------------------------------------------------------------------------------------------
 __global__ void train_encode_kernel(const float* __restrict__ o, const float* __restrict__ d,
-                                    const float* __restrict__ z, long long M, int S, long long Mp, int n_angles,
-                                    float* __restrict__ C4, float* __restrict__ C8) {
+                                    const float* __restrict__ z, long long row0, long long M, int S, long long Mp,
+                                    int n_angles, int xyz_mode, float* __restrict__ C4, float* __restrict__ C8) {
+    // local row m of this chunk = global sample row row0 + m; xyz_mode: o = xyz (M,3), d = view_dirs (M,3) or null
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mp) return;
     float* ex = C4 + m * kLdC4 + 256;
@@ -366,12 +367,21 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
         for (int i = 0; i < kDirPad; ++i) ed[i] = 0.f;
         return;
     }
-    const long long r = m / S;
-    const float zz = z[m];
+    const long long gm = row0 + m;
     const float kPi = 3.1415927410125732f;
-    const float4 oo = reinterpret_cast<const float4*>(o)[r], dd = reinterpret_cast<const float4*>(d)[r];
-    const float p[3] = {__fadd_rn(oo.x, __fmul_rn(dd.x, zz)), __fadd_rn(oo.y, __fmul_rn(dd.y, zz)),
-                        __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
+    float p[3], v3[3] = {0.f, 0.f, 0.f};
+    if (xyz_mode) {
+        p[0] = o[gm * 3 + 0]; p[1] = o[gm * 3 + 1]; p[2] = o[gm * 3 + 2];
+        if (d) { v3[0] = d[gm * 3 + 0]; v3[1] = d[gm * 3 + 1]; v3[2] = d[gm * 3 + 2]; }
+    } else {
+        const long long r = gm / S;
+        const float zz = z[gm];
+        const float4 oo = reinterpret_cast<const float4*>(o)[r], dd = reinterpret_cast<const float4*>(d)[r];
+        p[0] = __fadd_rn(oo.x, __fmul_rn(dd.x, zz));
+        p[1] = __fadd_rn(oo.y, __fmul_rn(dd.y, zz));
+        p[2] = __fadd_rn(oo.z, __fmul_rn(dd.z, zz));
+        v3[0] = dd.x; v3[1] = dd.y; v3[2] = dd.z;
+    }
     for (int c = 0; c < 3; ++c) {
         ex[c * 11] = p[c];
         for (int k = 0; k < 5; ++k) {
@@ -381,8 +391,7 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
         }
     }
     for (int i = 33; i < kXyzPad; ++i) ex[i] = 0.f;
-    const float v3[3] = {dd.x, dd.y, dd.z};
-    const int ncomp = n_angles + 1;
+    const int ncomp = n_angles > 0 ? n_angles + 1 : 0;     // the xyz-only network has no direction input
     for (int c = 0; c < ncomp; ++c) {
         const float v = n_angles == 2 ? v3[c] : (c == 0 ? v3[0] : v3[2]);
         for (int k = 0; k < 4; ++k) {
@@ -394,10 +403,10 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
     for (int i = ncomp * 8; i < kDirPad; ++i) ed[i] = 0.f;
 }
 
-void launch_train_encode(const float* o, const float* d, const float* z, long long N, int S, long long Mp,
-                         int n_angles, float* C4, float* C8, hipStream_t s) {
-    hipLaunchKernelGGL(train_encode_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, o, d, z, N * S, S,
-                       Mp, n_angles, C4, C8);
+void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
+                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s) {
+    hipLaunchKernelGGL(train_encode_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, o, d, z, row0, M, S, Mp,
+                       n_angles, xyz_mode, C4, C8);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -288,6 +288,10 @@ class Context:
     def model_predict(self, which, xyz, view_dirs):
         arr = self._arrays(xyz, view_dirs)
         m = int(xyz.shape[0])
+        if self.cfg.n_angles == 0:                      # xyz-only network: no direction input (UtilsNRF.py:229-234)
+            out, p = arr.out((m, 4))
+            _lib.check(self.lib.nerf_model_predict(self.h, which, arr.inp(xyz, (m, 3)), None, m, p, arr.mem))
+            return out
         if self.cfg.n_angles == 1 and tuple(view_dirs.shape) == (m, 2):
             # the reference hands (x, z) to the n_angles == 1 network (src/UtilsCV.py:134-135); the
             # library takes full directions and ignores y through zero-packed weights
@@ -505,7 +509,7 @@ def render_rays(model: NetHandle, rays_orig, rays_dirs, z_values, n_pos_enc_for_
                 n_angles_for_model: int):
     """src/UtilsNeuralRadianceField.py:181-211 -> (render_result, weights, cumprod, alpha, rgb)."""
     cfg = model.ctx.cfg
-    if n_angles_for_model not in (1, 2):
+    if n_angles_for_model not in (0, 1, 2):    # 0: render_rays never calls get_view_directions (UtilsNRF.py:205)
         raise Exception(f"{N_ANGLES_FOR_MODEL} should be 1 or 2.")   # src/UtilsCV.py:138
     if (n_pos_enc_for_xyz, n_pos_enc_for_angles, n_angles_for_model) != (cfg.n_pos_enc_xyz, cfg.n_pos_enc_dir,
                                                                          cfg.n_angles):
@@ -515,8 +519,8 @@ def render_rays(model: NetHandle, rays_orig, rays_dirs, z_values, n_pos_enc_for_
 
 def model_predict(model: NetHandle, n_enc_phi_theta: int, n_pos_enc_for_xyz: int, xyz, view_dirs=None):
     """src/UtilsNeuralRadianceField.py:214-234 -> (M,4) raw (R,G,B,Sigma)."""
-    if view_dirs is None:
-        raise NotImplementedError("n_angles_for_model == 0 network is not built yet")
+    if view_dirs is None and model.ctx.cfg.n_angles != 0:
+        raise ValueError("view_dirs is None but this model takes view directions")
     return model.ctx.model_predict(model.which, xyz, view_dirs)
 
 

@@ -40,9 +40,19 @@ def layer_shapes(n_pos_enc_xyz: int = 5, n_pos_enc_dir: int = 4, n_angles: int =
     src/NeRF.py:312-339.  Order == Keras ``model.get_weights()`` order (kernel then bias
     per layer): dense, dense_1..dense_10.
     """
+    dim_xyz = 3 + 3 * 2 * n_pos_enc_xyz                      # src/NeRF.py:312
+    if n_angles == 0:
+        # get_network_only_xyz, src/NeRF.py:248-288: 12 Dense layers in creation order
+        return [
+            (dim_xyz, hidden), (hidden, hidden), (hidden, hidden), (hidden, hidden),       # :266-269
+            (dim_xyz + hidden, hidden), (hidden, hidden), (hidden, hidden), (hidden, hidden),  # :271-275
+            (hidden, hidden),                                    # :277  dense_full(sigma_out_full_dense)
+            (hidden, last_hidden),                               # :278
+            (last_hidden, 3),                                    # :280
+            (hidden, 1),                                         # :283  sigma from sigma_out_full_dense
+        ]
     if n_angles not in (1, 2):
         raise ValueError("n_angles_for_model should be 1 or 2.")  # src/UtilsCV.py:138
-    dim_xyz = 3 + 3 * 2 * n_pos_enc_xyz                      # src/NeRF.py:312
     dim_dir = n_pos_enc_dir * 2 * (n_angles + 1)             # src/NeRF.py:313-314
     return [
         (dim_xyz, hidden), (hidden, hidden), (hidden, hidden), (hidden, hidden),   # :319-322
@@ -182,7 +192,8 @@ def sample_along_rays(origin: np.ndarray, dirs: np.ndarray, z: np.ndarray) -> np
 
 
 def get_view_directions(n_samples: int, dirs: np.ndarray, n_angles: int) -> np.ndarray:
-    """src/UtilsCV.py:124-143 -> (N*S, n_angles+1): raw (un-normalised) direction per sample."""
+    """src/UtilsCV.py:124-143 -> (N*S, n_angles+1): raw (un-normalised) direction per sample.
+    (render_rays passes None instead for the xyz-only network, UtilsNeuralRadianceField.py:205.)"""
     if n_angles == 1:
         idx = [0, 2]
     elif n_angles == 2:
@@ -266,9 +277,28 @@ def leaky_relu(x: np.ndarray, alpha: float) -> np.ndarray:
     return np.maximum(x, F32(alpha) * x)
 
 
+def mlp_forward_xyz_only(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.ndarray,
+                         alpha: float = 0.05) -> np.ndarray:
+    """get_network_only_xyz, src/NeRF.py:265-287: (M,33) -> (M,4) raw [r,g,b,sigma]."""
+    h = leaky_relu(xyz_enc @ layers[0][0] + layers[0][1], alpha)
+    for k, b in layers[1:4]:
+        h = leaky_relu(h @ k + b, alpha)
+    h = leaky_relu(np.concatenate([xyz_enc, h], axis=-1) @ layers[4][0] + layers[4][1], alpha)   # :271 [xyz, hidden]
+    for k, b in layers[5:8]:
+        h = leaky_relu(h @ k + b, alpha)
+    sigma_feat = h                                           # :275 sigma_out_full_dense
+    h = leaky_relu(sigma_feat @ layers[8][0] + layers[8][1], alpha)      # :277
+    h = leaky_relu(h @ layers[9][0] + layers[9][1], alpha)               # :278
+    rgb = h @ layers[10][0] + layers[10][1]                  # :280
+    sigma = sigma_feat @ layers[11][0] + layers[11][1]       # :283
+    return np.concatenate([rgb, sigma], axis=-1).astype(F32)  # :286
+
+
 def mlp_forward(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.ndarray,
                 dir_enc: np.ndarray, alpha: float = 0.05) -> np.ndarray:
     """src/NeRF.py:316-339: (M,33),(M,24) -> (M,4) raw [r,g,b,sigma]."""
+    if len(layers) == 12:
+        return mlp_forward_xyz_only(layers, xyz_enc, alpha)
     (k0, b0), (k1, b1), (k2, b2), (k3, b3), (k4, b4), (k5, b5), (k6, b6), (k7, b7), \
         (k8, b8), (k9, b9), (k10, b10) = layers
     h = leaky_relu(xyz_enc @ k0 + b0, alpha)
@@ -290,8 +320,8 @@ def model_predict(layers, xyz: np.ndarray, view_dirs: np.ndarray, n_pos_enc_xyz:
     out = np.empty((xyz.shape[0], 4), F32)
     for a in range(0, xyz.shape[0], chunk):
         b = min(a + chunk, xyz.shape[0])
-        out[a:b] = mlp_forward(layers, positional_encoding_for_xyz(xyz[a:b], n_pos_enc_xyz),
-                               positional_encoding_for_views(view_dirs[a:b], n_pos_enc_dir), alpha)
+        dir_enc = None if view_dirs is None else positional_encoding_for_views(view_dirs[a:b], n_pos_enc_dir)
+        out[a:b] = mlp_forward(layers, positional_encoding_for_xyz(xyz[a:b], n_pos_enc_xyz), dir_enc, alpha)
     return out
 
 
@@ -327,7 +357,7 @@ def render_rays(layers, rays_orig, rays_dirs, z_values, n_pos_enc_xyz=5, n_pos_e
     """src/UtilsNeuralRadianceField.py:181-211 -> (rgb, weights, cumprod, alpha, rgb_samples)."""
     o = np.asarray(rays_orig, F32); d = np.asarray(rays_dirs, F32); z = np.asarray(z_values, F32)
     coords = sample_along_rays(o, d, z)[..., :3]             # :204
-    view = get_view_directions(z.shape[1], d, n_angles)      # :205
+    view = None if n_angles == 0 else get_view_directions(z.shape[1], d, n_angles)      # :205
     pred = model_predict(layers, coords.reshape(-1, 3), view, n_pos_enc_xyz, n_pos_enc_dir, alpha)
     pred = pred.reshape(z.shape[0], z.shape[1], 4)           # :207-209
     return ray_marching(pred, z)                             # :210

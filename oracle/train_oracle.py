@@ -57,6 +57,17 @@ def _pe(x: torch.Tensor, n_enc: int, passthrough: bool) -> torch.Tensor:
 def _mlp(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float):
     """src/NeRF.py:316-339."""
     lrelu = lambda t: torch.nn.functional.leaky_relu(t, alpha)
+    if len(p) == 24:                                  # get_network_only_xyz, src/NeRF.py:265-287
+        h = lrelu(xyz_enc @ p[0] + p[1])
+        for i in (1, 2, 3):
+            h = lrelu(h @ p[2 * i] + p[2 * i + 1])
+        h = lrelu(torch.cat([xyz_enc, h], -1) @ p[8] + p[9])
+        for i in (5, 6, 7):
+            h = lrelu(h @ p[2 * i] + p[2 * i + 1])
+        feat = h
+        h = lrelu(feat @ p[16] + p[17])
+        h = lrelu(h @ p[18] + p[19])
+        return torch.cat([h @ p[20] + p[21], feat @ p[22] + p[23]], -1)
     h = lrelu(xyz_enc @ p[0] + p[1])
     for i in (1, 2, 3):
         h = lrelu(h @ p[2 * i] + p[2 * i + 1])
@@ -76,7 +87,8 @@ def _render_rays(p, o, d, z, n_xyz, n_dir, n_angles, alpha):
     pts = (o[:, None, :3] + d[:, None, :3] * z[..., None]).reshape(-1, 3)
     comps = [0, 1, 2] if n_angles == 2 else [0, 2]                   # src/UtilsCV.py:124-143
     view = d[:, comps][:, None, :].expand(n, s, len(comps)).reshape(-1, len(comps))
-    raw = _mlp(p, _pe(pts, n_xyz, True), _pe(view, n_dir, False), alpha).reshape(n, s, 4)
+    dir_enc = None if n_angles == 0 else _pe(view, n_dir, False)     # UtilsNeuralRadianceField.py:205
+    raw = _mlp(p, _pe(pts, n_xyz, True), dir_enc, alpha).reshape(n, s, 4)
     sigma = torch.relu(raw[..., 3])
     c = torch.sigmoid(raw[..., :3])
     delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 1e9, dtype=z.dtype)], -1)

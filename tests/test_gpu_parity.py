@@ -584,3 +584,35 @@ def test_nonfinite_watch(golden_ckpt, golden_vec):
     out = ctx.render_rays(0, o, d, z)
     assert ctx.read_nonfinite() == 0 and np.isfinite(out[0]).all()
     ctx.close()
+
+
+def test_xyz_only_network(oracle):
+    """n_angles_for_model == 0 (get_network_only_xyz, src/NeRF.py:248-288; 5 of the reference's configs): 12 Dense
+    layers, sigma from the 8th hidden layer, no direction input.  Served by the layer-wise fp32 MFMA GEMM path
+    (no fused kernel is built for this network): model_predict, render_rays and the two-pass render vs the oracle."""
+    import nerf_and_dietnerf_amd as N
+    near, far = 0.5, 2.5
+    ctx = N.Context(n_angles=0, near=near, far=far)
+    bc, bf = N.glorot_blob(5, n_angles=0), N.glorot_blob(6, n_angles=0)
+    bc[-1] = bf[-1] = 1.5                                   # lift sigma so that the compositing is not trivial
+    ctx.load_weights(0, bc)
+    ctx.load_weights(1, bf)
+    coarse, fine = oracle.unpack_blob(bc, n_angles=0), oracle.unpack_blob(bf, n_angles=0)
+    rng = np.random.default_rng(8)
+    n, sc, sf = 333, 24, 40                                 # 333*24 rows: not a multiple of the 128-row tile
+    c2w = oracle.get_sphere_matrix(1.0, -25, 40, 0).astype(np.float32)
+    d = oracle.get_rays_directions(20, 20, 0.5, c2w).reshape(-1, 4)[:n]
+    o = np.tile(c2w[:, 3], (n, 1)).astype(np.float32)
+    uc, uf = rng.random((n, sc), dtype=np.float32), rng.random((n, sf), dtype=np.float32)
+    xyz = rng.standard_normal((1000, 3)).astype(np.float32)
+    raw = ctx.model_predict(0, xyz, None)
+    ref_raw = oracle.model_predict(coarse, xyz, None)
+    assert np.abs(raw - ref_raw).max() <= 2e-5 * max(1.0, np.abs(ref_raw).max())
+    out = ctx.render(o, d, sc, sf, uc, uf)
+    ref = oracle.render(coarse, fine, o, d, near, far, uc, uf, n_angles=0)
+    assert np.abs(out[0] - ref[0]).max() <= RGB_TOL
+    assert np.abs(out[5] - ref[5]).max() <= 2e-5             # depths: the sampler sees weights that differ by ulps
+    assert np.abs(out[1] - ref[1]).max() <= 2e-5
+    with pytest.raises(RuntimeError, match="layer-wise fp32 path"):
+        ctx.set_precision("f16x3")
+    ctx.close()

@@ -296,3 +296,37 @@ def test_data_parallel_gradients_equal_full_batch(oracle, golden_ckpt):
     for rank, gc, gf, w in res:
         assert _relerr(gc, gc_full) <= 1e-5 and _relerr(gf, gf_full) <= 1e-5, rank
     np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+def test_xyz_only_network_gradients_and_steps(oracle):
+    """Training of the xyz-only network (n_angles_for_model = 0): gradients vs the oracle with alpha = 1
+    (smooth: 2e-4 bar) and a few steps that lower the loss; the render path then sees the trained weights."""
+    from oracle import train_oracle as T
+    import nerf_and_dietnerf_amd as N
+    n, sc, sf = 40, 12, 20
+    o, d, rng = _rays(oracle, n, 6)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    u_c, u_f = rng.random((n, sc), dtype=np.float32), rng.random((n, sf), dtype=np.float32)
+    bc, bf = N.glorot_blob(21, n_angles=0), N.glorot_blob(22, n_angles=0)
+    bc[-1] = bf[-1] = 1.5
+    near, far = 0.5, 2.5
+    for alpha, tol, cmin in ((1.0, 2e-4, 0.9999999), (0.05, 5e-2, 0.999)):
+        ctx = N.Context(near=near, far=far, n_angles=0, leaky_relu_alpha=alpha)
+        ctx.load_weights(0, bc)
+        ctx.load_weights(1, bf)
+        ctx.train_begin(1e-3)
+        m, gc, gf = ctx.train_gradients(o, d, tgt, sc, sf, u_c, u_f)
+        r = T.train_gradients(bc, bf, o, d, tgt, near, far, u_c, u_f, n_angles=0, alpha=alpha)
+        assert abs(m["loss"] - r["loss"]) <= 2e-6 * r["loss"]
+        assert _relerr(gc, r["grad_coarse"]) <= tol and _cos(gc, r["grad_coarse"]) > cmin
+        assert _relerr(gf, r["grad_fine"]) <= tol and _cos(gf, r["grad_fine"]) > cmin
+        if alpha == 0.05:
+            losses = [ctx.train_step(o, d, tgt, sc, sf, u_c, u_f)["loss"] for _ in range(20)]
+            assert losses[-1] < 0.7 * losses[0]
+            ctx.train_end()
+            out = ctx.render(o, d, sc, sf, u_c, u_f)
+            wc, wf = ctx.get_weights(0), ctx.get_weights(1)
+            ref = oracle.render(oracle.unpack_blob(wc, n_angles=0), oracle.unpack_blob(wf, n_angles=0), o, d, near,
+                                far, u_c, u_f, n_angles=0)
+            assert np.abs(out[0] - ref[0]).max() <= 1e-4
+        ctx.close()

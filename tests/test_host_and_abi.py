@@ -74,7 +74,10 @@ def test_weights_helpers(oracle):
     layers = oracle.unpack_blob(b)
     assert all(np.all(bias == 0) for _, bias in layers)
     with pytest.raises(Exception, match="should be 1 or 2"):
-        N.layer_shapes(n_angles=0)
+        N.layer_shapes(n_angles=3)
+    # the xyz-only network (get_network_only_xyz, src/NeRF.py:248-288): 12 Dense layers
+    assert N.layer_shapes(n_angles=0) == oracle.layer_shapes(n_angles=0) and len(N.layer_shapes(n_angles=0)) == 12
+    assert N.blob_size(n_angles=0) == 577028
 
 
 def test_ray_slab_partition():
