@@ -14,6 +14,8 @@ from .render import (Context, NeRF, NetHandle, default_context, get_rays_directi
 from .keras_h5 import load_nerf_checkpoint, read_keras_weights
 from .sharding import allreduce_mean, dist_world, gather_slabs, ray_slab, render_image_sharded
 from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
+from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
+                       poses_avg, recenter_poses, spherify_poses)
 from .video import (get_l_to_r_c2w_matrices, get_sphere_matrices, get_sphere_matrix, histogram_equalize_depth,
                     render_video)
 from .weights import blob_size, glorot_blob, layer_shapes

@@ -94,5 +94,18 @@ def main(out):
                         recorded_psnr_train=psn[1, -1])
 
 
+def copy_dataset(dst):
+    """The 50 px Alexander dataset itself (71 JPG of ~2 KB + poses_bounds.npy: data files) and the recorded
+    per-epoch PSNR history of the shipped run -> tests/golden/alexander50/ (for the loader and trainer tests)."""
+    import shutil
+    os.makedirs(dst, exist_ok=True)
+    for n in sorted(os.listdir(DATASET)):
+        if n.endswith(("JPG", "jpg", "png", "npy")):
+            shutil.copyfile(os.path.join(DATASET, n), os.path.join(dst, n))
+    psn = np.load(RUN + "/saved_test_train_psnrs/psnrs_train_test_095.npy", allow_pickle=False)
+    np.save(os.path.join(os.path.dirname(dst), "alexander50_recorded_psnrs.npy"), psn.astype(np.float32))
+
+
 if __name__ == "__main__":
+    copy_dataset(os.path.join(os.path.dirname(__file__), "alexander50"))
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "alexander50_epoch095.npz"))

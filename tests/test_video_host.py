@@ -1,5 +1,6 @@
 """Host side of the video loop (nerf_and_dietnerf_amd/video.py): camera paths and depth tone-mapping."""
 import numpy as np
+import pytest
 
 
 def test_sphere_matrices(oracle):
@@ -38,3 +39,56 @@ def test_histogram_equalize_depth():
     assert h.min() > 0.6 * h.mean()
     assert d.min() >= 0.5                                             # the input is not modified
     np.testing.assert_array_equal(video.histogram_equalize_depth(np.zeros((4, 4))), np.zeros((4, 4)))
+
+
+def test_colmap_loader_matches_fixture_constants(golden_ckpt):
+    """get_data_from_colmap on the 50 px Alexander dataset (data files copied under tests/golden/alexander50 by
+    tests/golden/make_fixtures.py) == the constants the fixture script derived independently with h5py/imageio
+    (and SURVEY.md section 8c): scale, near, far, fov, the two poses and -- decoded by Pillow here, imageio there --
+    the two images."""
+    import os
+    import nerf_and_dietnerf_amd as N
+    root = os.path.join(os.path.dirname(__file__), "golden", "alexander50")
+    images, poses, fov, near, far, avg, scale = N.get_data_from_colmap(root)
+    assert images.shape == (71, 50, 50, 3) and images.dtype == np.float32 and 0.0 <= images.min() and images.max() <= 1.0
+    assert poses.shape == (71, 4, 4) and poses.dtype == np.float32
+    assert abs(scale - float(golden_ckpt["scale"])) < 1e-12 and abs(scale - 0.1867401) < 1e-6
+    assert near == float(golden_ckpt["near"]) and far == float(golden_ckpt["far"])
+    assert abs(fov - float(golden_ckpt["fov"])) < 1e-12 and np.float32(fov) == np.float32(float(golden_ckpt["fov"]))
+    np.testing.assert_array_equal(poses[19], golden_ckpt["c2w_test"])
+    np.testing.assert_array_equal(poses[4], golden_ckpt["c2w_train"])
+    # JPEG decoders differ in chroma upsampling / IDCT (Pillow 12 here, imageio 2.9 + its libjpeg in the fixture
+    # script): same pictures to > 30 dB, not bit-identical
+    for got, want in ((images[19], golden_ckpt["img_test"]), (images[4], golden_ckpt["img_train"])):
+        mse = np.mean((got - want.astype(np.float32) / 255.0) ** 2)
+        assert -10 * np.log10(mse) > 30.0
+    assert np.abs(np.linalg.norm(poses[:, :3, 3], axis=1)).max() == pytest.approx(1.0, abs=1e-6)   # spherified
+    assert avg.shape == (4, 4)
+    idx = N.get_train_images_indices(71, 19)
+    assert len(idx) == 70 and 19 not in idx
+    assert N.get_train_images_indices(71, 19, [0, 2, 19, 4]) == [0, 2, 4]
+
+
+def test_blender_loader_semantics(tmp_path):
+    """get_data_from_blender on a synthetic cam_data.json: recentred on the average pose, farthest camera on the
+    unit sphere, near/far scaled along."""
+    import json
+    from PIL import Image
+    import nerf_and_dietnerf_amd as N
+    rng = np.random.default_rng(0)
+    frames = []
+    for i in range(5):
+        m = N.get_sphere_matrix(3.0, -30.0 + 7 * i, 40.0 * i, 0.0)
+        name = f"im_{i:02d}.png"
+        Image.fromarray(rng.integers(0, 255, (6, 8, 3), dtype=np.uint8)).save(tmp_path / name)
+        frames.append({"filename": name, "transformation_matrix": m.tolist()})
+    (tmp_path / "cam_data.json").write_text(json.dumps({"focal_length": 50.0, "field_of_view": 0.69, "frames": frames}))
+    images, cams, fov, near, far, avg, scale = N.get_data_from_blender(tmp_path, 2.0, 6.0)
+    assert images.shape == (5, 6, 8, 3) and images.max() <= 1.0 and fov == 0.69
+    r = np.linalg.norm(cams[:, :3, 3], axis=1)
+    assert r.max() == pytest.approx(1.0, abs=1e-6)
+    assert near == pytest.approx(2.0 * scale) and far == pytest.approx(6.0 * scale)
+    # recentring: the average of the recentred poses is the identity frame
+    pa = N.poses_avg(cams.astype(np.float64))
+    np.testing.assert_allclose(pa[:, :3], np.eye(3), atol=1e-6)
+    np.testing.assert_allclose(pa[:, 3], 0.0, atol=1e-6)
