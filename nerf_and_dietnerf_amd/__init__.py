@@ -11,7 +11,7 @@ from ._lib import (NERF_MEM_DEVICE, NERF_MEM_HOST, NERF_NET_COARSE, NERF_NET_FIN
 from .render import (Context, NeRF, NetHandle, default_context, get_rays_directions, get_size_of_splits,
                      get_z_vals_from_prob_dist_func, get_z_values, model_predict, positional_encoding_for_views,
                      positional_encoding_for_xyz, ray_marching, render_rays, split_to_batches)
-from .keras_h5 import load_nerf_checkpoint, read_keras_weights
+from .keras_h5 import load_nerf_checkpoint, read_keras_weights, save_nerf_checkpoint, write_keras_weights
 from .sharding import allreduce_mean, dist_world, gather_slabs, ray_slab, render_image_sharded
 from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,

@@ -177,3 +177,155 @@ def load_nerf_checkpoint(path: str) -> Tuple[np.ndarray, np.ndarray]:
         raise ValueError("no model groups with Dense weights found")
     blobs = [np.concatenate([w.ravel() for w in models[n]]) for n in names[:2]]
     return blobs[0], (blobs[1] if len(blobs) > 1 else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# writer: model.save_weights(path) in the layout above (src/UtilsFiles.py:153-164) -- readable by h5py / Keras
+# ---------------------------------------------------------------------------------------------
+class _H5Writer:
+    """Minimal HDF5 emitter: superblock v0, version-1 object headers, old-style groups (one symbol-table node per
+    group: the superblock's group-leaf K is raised so that 2K >= the largest group), contiguous little-endian
+    float32 datasets, version-1 attributes holding fixed-length strings (scalar or 1-D)."""
+
+    LEAF_K = 32          # up to 64 members per group in one SNOD
+    INT_K = 16
+
+    def __init__(self):
+        self.buf = bytearray(b"\x00" * 96)     # superblock (56 + 40-byte root symbol-table entry), patched at the end
+
+    def _align(self, n=8):
+        self.buf += b"\x00" * (-len(self.buf) % n)
+
+    def _alloc(self, data: bytes) -> int:
+        self._align()
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    # ---- messages ----
+    @staticmethod
+    def _msg(mtype: int, body: bytes) -> bytes:
+        body += b"\x00" * (-len(body) % 8)
+        return struct.pack("<HHB3x", mtype, len(body), 0) + body
+
+    @staticmethod
+    def _dataspace(shape) -> bytes:
+        return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(s)) for s in shape)
+
+    @staticmethod
+    def _dtype_f32() -> bytes:
+        # class 1 (float) version 1; little-endian, implied-msb mantissa, sign bit 31; 32-bit IEEE layout
+        return struct.pack("<BBBBI", 0x11, 0x20, 0x1F, 0x00, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+
+    @staticmethod
+    def _dtype_str(n: int) -> bytes:
+        return struct.pack("<BBBBI", 0x13, 0x01, 0x00, 0x00, n)       # class 3 (string), null-padded, ASCII
+
+    def _attr(self, name: str, strings, scalar: bool) -> bytes:
+        vals = [s.encode("utf-8") for s in strings]
+        width = max([1] + [len(v) for v in vals])                      # an empty list gives a zero-length attribute
+        nm = name.encode("utf-8") + b"\x00"
+        dt = self._dtype_str(width)
+        ds = self._dataspace(() if scalar else (len(vals),))
+        pad = lambda b: b + b"\x00" * (-len(b) % 8)
+        body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(ds)) + pad(nm) + pad(dt) + pad(ds)
+        body += b"".join(v.ljust(width, b"\x00") for v in vals)
+        return self._msg(0x000C, body)
+
+    def _object_header(self, msgs) -> int:
+        body = b"".join(msgs)
+        return self._alloc(struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body)
+
+    # ---- objects ----
+    def dataset(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr, dtype="<f4")
+        data_addr = self._alloc(arr.tobytes())
+        layout = struct.pack("<BBQQ", 3, 1, data_addr, arr.nbytes)
+        fill = struct.pack("<BBBB", 2, 2, 0, 0)                        # fill value v2: allocate late, never write, undefined
+        return self._object_header([self._msg(0x0001, self._dataspace(arr.shape)), self._msg(0x0003, self._dtype_f32()),
+                                    self._msg(0x0005, fill), self._msg(0x0008, layout)])
+
+    def group(self, members: Dict[str, int], attrs=()) -> int:
+        """members: name -> object header address.  attrs: [(name, [strings], scalar)]."""
+        names = sorted(members)                                        # symbol-table entries are ordered by name
+        if len(names) > 2 * self.LEAF_K:
+            raise ValueError("group too large for a single symbol-table node")
+        heap_data = bytearray(b"\x00" * 8)                             # offset 0: the empty name
+        offs = {}
+        for n in names:
+            offs[n] = len(heap_data)
+            b = n.encode("utf-8") + b"\x00"
+            heap_data += b + b"\x00" * (-len(b) % 8)
+        heap_seg = self._alloc(bytes(heap_data))
+        heap = self._alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, heap_seg))   # free list: none (1)
+        snod = bytearray(b"SNOD" + struct.pack("<BBH", 1, 0, len(names)))
+        for n in names:
+            snod += struct.pack("<QQII16x", offs[n], members[n], 0, 0)
+        snod += b"\x00" * (8 + 2 * self.LEAF_K * 40 - len(snod))
+        snod_addr = self._alloc(bytes(snod))
+        tree = bytearray(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1 if names else 0, _UNDEF, _UNDEF))
+        tree += struct.pack("<Q", 0)                                   # key 0: the empty name
+        if names:
+            tree += struct.pack("<QQ", snod_addr, offs[names[-1]])     # child 0, key 1 = largest name in it
+        tree += b"\x00" * (24 + (2 * self.INT_K + 1) * 8 + 2 * self.INT_K * 8 - len(tree))
+        tree_addr = self._alloc(bytes(tree))
+        msgs = [self._msg(0x0011, struct.pack("<QQ", tree_addr, heap))]
+        msgs += [self._attr(n, v, sc) for n, v, sc in attrs]
+        return self._object_header(msgs), tree_addr, heap
+
+    def finish(self, root) -> bytes:
+        root_hdr, tree_addr, heap = root
+        self._align()
+        sb = _SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self.LEAF_K, self.INT_K, 0)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, len(self.buf), _UNDEF)
+        sb += struct.pack("<QQII", 0, root_hdr, 1, 0) + struct.pack("<QQ", tree_addr, heap)
+        assert len(sb) == 96
+        self.buf[:96] = sb
+        return bytes(self.buf)
+
+
+def write_keras_weights(path: str, models: Dict[str, List[np.ndarray]], first_dense_index: int = 0,
+                        keras_version: str = "2.7.0") -> None:
+    """``models``: {"model": [kernel, bias, ...], "model_1": [...]} in ``get_weights()`` order -> a Keras-2.7 style
+    weights file: groups ``model`` / ``model_1`` (+ the empty ``top_level_model_weights``), per Dense layer a group
+    ``dense_<k>`` with ``kernel:0`` and ``bias:0``; Dense layers are numbered consecutively across the models as
+    Keras names them; attributes ``layer_names`` / ``backend`` / ``keras_version`` on the root and ``weight_names`` on
+    every model group (fixed-length strings)."""
+    w = _H5Writer()
+    k = first_dense_index
+    root_members = {}
+    for gname in sorted(models, key=_suffix):
+        tensors = models[gname]
+        if len(tensors) % 2:
+            raise ValueError("expected kernel/bias pairs")
+        layers, weight_names = {}, []
+        for i in range(0, len(tensors), 2):
+            lname = "dense" if k == 0 else f"dense_{k}"
+            k += 1
+            kaddr, baddr = w.dataset(tensors[i]), w.dataset(tensors[i + 1])
+            layers[lname] = w.group({"kernel:0": kaddr, "bias:0": baddr})[0]
+            weight_names += [f"{lname}/kernel:0", f"{lname}/bias:0"]
+        root_members[gname] = w.group(layers, [("weight_names", weight_names, False)])[0]
+    root_members["top_level_model_weights"] = w.group({}, [("weight_names", [], False)])[0]     # empty, as Keras writes
+    root = w.group(root_members, [("layer_names", sorted(models, key=_suffix), False), ("backend", ["tensorflow"], True),
+                                  ("keras_version", [keras_version], True)])
+    with open(path, "wb") as f:
+        f.write(w.finish(root))
+
+
+def save_nerf_checkpoint(path: str, coarse_blob: np.ndarray, fine_blob=None, **shape_kw) -> None:
+    """Inverse of load_nerf_checkpoint: flat ``get_weights()``-order blobs -> ``NeRF_model_epoch_XXX.h5``."""
+    from .weights import layer_shapes
+    models = {}
+    for name, blob in (("model", coarse_blob), ("model_1", fine_blob)):
+        if blob is None:
+            continue
+        blob = np.asarray(blob, np.float32).ravel()
+        tensors, off = [], 0
+        for i, o in layer_shapes(**shape_kw):
+            tensors.append(blob[off:off + i * o].reshape(i, o)); off += i * o
+            tensors.append(blob[off:off + o]); off += o
+        if off != blob.size:
+            raise ValueError(f"weight blob has {blob.size} floats, expected {off}")
+        models[name] = tensors
+    write_keras_weights(path, models)

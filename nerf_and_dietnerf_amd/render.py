@@ -421,6 +421,14 @@ class NeRF:
         coarse, fine = load_nerf_checkpoint(str(path))
         self.set_weights(coarse, fine)
 
+    def save_weights(self, path) -> None:
+        """Keras ``model.save_weights(path)`` (src/UtilsFiles.py:153-164): the current (trained) weights as a
+        Keras-2.7 style ``.h5`` that h5py / the reference's ``model.load_weights`` read."""
+        from .keras_h5 import save_nerf_checkpoint
+        coarse, fine = self.get_weights()
+        save_nerf_checkpoint(str(path), coarse, fine, n_pos_enc_xyz=self.n_pos_enc_dim_xyz,
+                             n_pos_enc_dir=self.n_pos_enc_view_dir, n_angles=self.n_angles_for_model)
+
     @staticmethod
     def get_nerf_model_path(save_location, epoch_number: int):
         """src/NeRF.py:342-351."""

@@ -369,3 +369,27 @@ def test_training_reproduces_the_recorded_psnr_curve(capsys):
               "\n[recorded curve] reference " + " ".join(f"{x:5.2f}" for x in recorded[:8]))
     assert diff.max() <= 2.0 and diff.mean() <= 1.0
     model.ctx.close()
+
+
+def test_save_weights_after_training(oracle, golden_ckpt, tmp_path):
+    """NeRF.save_weights after optimizer steps -> .h5 -> a second model loads it and renders the same pixels."""
+    import nerf_and_dietnerf_amd as N
+    p = _problem(oracle, golden_ckpt, n=32, sc=8, sf=8, seed=9)
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2}
+    ren_cfg = {"n_render_samples_coarse": 8, "n_render_samples_fine": 8}
+    a = N.NeRF(net_cfg, ren_cfg, p["near"], p["far"])
+    a.set_weights(p["bc"], p["bf"])
+    a.compile(1e-3)
+    for _ in range(3):
+        a.train_step((p["o"], p["d"], p["tgt"]), u_coarse=p["u_c"], u_fine=p["u_f"])
+    path = N.NeRF.get_nerf_model_path(tmp_path, 7)
+    path.parent.mkdir(parents=True)
+    a.save_weights(path)
+    b = N.NeRF(net_cfg, ren_cfg, p["near"], p["far"])
+    b.load_weights(path)
+    ra = a.render(p["o"], p["d"], u_coarse=p["u_c"], u_fine=p["u_f"])[0]
+    rb = b.render(p["o"], p["d"], u_coarse=p["u_c"], u_fine=p["u_f"])[0]
+    np.testing.assert_array_equal(ra, rb)
+    assert np.abs(a.get_weights()[0] - p["bc"]).max() > 1e-4
+    a.ctx.close(); b.ctx.close()
