@@ -24,27 +24,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // gemm_abt
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsLd = 20;   // floats per staged row of 16 (80 B: keeps float4 alignment, spreads banks)
+// LDS tiles are k-major: element (k, row) of a [rows x 16] operand tile sits at k * (rows + 4) + row, so that the
+// MFMA operand reads (lane = row, 8 k values per lane half) are 8 conflict-free ds_read_b32 -- consecutive lanes hit
+// consecutive banks, the two lane halves (k + 8) land 32 banks apart -- and the transposing stores (4 dwords of one
+// row each) spread over all 64 banks.  (A row-major tile read with ds_read_b128 measured 0.37 bank-conflict cycles
+// per busy cycle: SQ_LDS_BANK_CONFLICT, rocprofv3 --pmc.)
 
-// One k-step (16) of the workgroup tile: operands from LDS buffer `buf` into the wave's MFMA tiles.
-template <int WTM, int WTN>
+// One k-step (16) of the workgroup tile: operands from one LDS buffer into the wave's MFMA tiles.
+template <int WTM, int WTN, int LDA, int LDB>
 __device__ __forceinline__ void abt_compute(const float* As, const float* Bs, int a_row0, int b_row0, int li, int lh,
                                             f32x16 (&acc)[WTM][WTN]) {
-    // lane (li, lh) holds k = 8*lh + j for MFMA step j: two float4 per operand tile
     float av[WTM][8], bv[WTN][8];
 #pragma unroll
-    for (int a = 0; a < WTM; ++a) {
-        const float* p = As + (a_row0 + a * 32 + li) * kLdsLd + 8 * lh;
-        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-        av[a][0] = x.x; av[a][1] = x.y; av[a][2] = x.z; av[a][3] = x.w;
-        av[a][4] = y.x; av[a][5] = y.y; av[a][6] = y.z; av[a][7] = y.w;
-    }
+    for (int j = 0; j < 8; ++j) {
 #pragma unroll
-    for (int b = 0; b < WTN; ++b) {
-        const float* p = Bs + (b_row0 + b * 32 + li) * kLdsLd + 8 * lh;
-        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-        bv[b][0] = x.x; bv[b][1] = x.y; bv[b][2] = x.z; bv[b][3] = x.w;
-        bv[b][4] = y.x; bv[b][5] = y.y; bv[b][6] = y.z; bv[b][7] = y.w;
+        for (int a = 0; a < WTM; ++a) av[a][j] = As[(8 * lh + j) * LDA + a_row0 + a * 32 + li];
+#pragma unroll
+        for (int b = 0; b < WTN; ++b) bv[b][j] = Bs[(8 * lh + j) * LDB + b_row0 + b * 32 + li];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -55,13 +51,21 @@ __device__ __forceinline__ void abt_compute(const float* As, const float* Bs, in
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
 }
 
+__device__ __forceinline__ void park4(float* tile, int ld, int k4, int row, const float4& v) {
+    tile[(k4 + 0) * ld + row] = v.x;
+    tile[(k4 + 1) * ld + row] = v.y;
+    tile[(k4 + 2) * ld + row] = v.z;
+    tile[(k4 + 3) * ld + row] = v.w;
+}
+
 template <int WTM, int WTN, int WVM, int WVN, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_abt_kernel(const GemmAbt g) {
     constexpr int TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
+    constexpr int LDA = TM + 4, LDB = TN + 4;
     static_assert(WVM * WVN == 4 && TM == 128, "4 waves, 128 rows per workgroup");
     static_assert(TN * 4 % 256 == 0 || TN * 4 < 256, "B tile: whole float4 rounds, or a single partial one");
-    __shared__ __attribute__((aligned(16))) float As[2][TM * kLdsLd];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TN * kLdsLd];
+    __shared__ __attribute__((aligned(16))) float As[2][16 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
     const int li = lane & 31, lh = lane >> 5;
@@ -71,11 +75,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     constexpr int B_F4 = TN * 4 >= 256 ? TN * 4 / 256 : 1;
     constexpr bool B_PARTIAL = TN * 4 < 256;              // narrow tile: only the first TN*4 threads stage B
     const bool b_on = !B_PARTIAL || t < TN * 4;
-    // staging slots of this thread (fixed): float4 #(t + 256 i) of a [rows x 16] tile
-    const int srow = t >> 2, skq = t & 3;
-    const float* ap = g.A + (m0 + srow) * g.lda + 4 * skq;
-    const float* bp = g.Bt + (size_t)(n0 + (B_PARTIAL ? (srow % TN) : srow)) * g.ldb + 4 * skq;
-    const int soff = srow * kLdsLd + 4 * skq;
+    // staging slots of this thread (fixed): float4 #(t + 256 i) of a [rows x 16] tile = row (t >> 2) + 64 i, k 4 (t & 3)
+    const int srow = t >> 2, sk4 = 4 * (t & 3);
+    const float* ap = g.A + (m0 + srow) * g.lda + sk4;
+    const float* bp = g.Bt + (size_t)(n0 + (B_PARTIAL ? (srow % TN) : srow)) * g.ldb + sk4;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -100,13 +103,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         rb3 = *reinterpret_cast<const float4*>(bp + 3 * b1 + (K0));                        \
     }
 #define ABT_PARK(BUF)                                                                      \
-    *reinterpret_cast<float4*>(&As[BUF][soff]) = ra0;                                      \
-    *reinterpret_cast<float4*>(&As[BUF][soff + 64 * kLdsLd]) = ra1;                        \
-    if (b_on) *reinterpret_cast<float4*>(&Bs[BUF][soff]) = rb0;                            \
-    if (B_F4 >= 2) *reinterpret_cast<float4*>(&Bs[BUF][soff + 64 * kLdsLd]) = rb1;         \
+    park4(As[BUF], LDA, sk4, srow, ra0);                                                   \
+    park4(As[BUF], LDA, sk4, srow + 64, ra1);                                              \
+    if (b_on) park4(Bs[BUF], LDB, sk4, srow, rb0);                                         \
+    if (B_F4 >= 2) park4(Bs[BUF], LDB, sk4, srow + 64, rb1);                               \
     if (B_F4 == 4) {                                                                       \
-        *reinterpret_cast<float4*>(&Bs[BUF][soff + 128 * kLdsLd]) = rb2;                   \
-        *reinterpret_cast<float4*>(&Bs[BUF][soff + 192 * kLdsLd]) = rb3;                   \
+        park4(Bs[BUF], LDB, sk4, srow + 128, rb2);                                         \
+        park4(Bs[BUF], LDB, sk4, srow + 192, rb3);                                         \
+    }
+    // data-gradient epilogue: the LeakyReLU' mask comes from the stored activation H.  Fetching it here, before the
+    // k loop, hides the 64 scattered loads per lane behind the MFMAs (fetched in the epilogue they were the kernel's
+    // main stall: SQ_WAIT_ANY 0.52 of the wave cycles).
+    float hmask[WTM][WTN][16];
+    if (EPI == EPI_BWD_MASK) {
+#pragma unroll
+        for (int a = 0; a < WTM; ++a)
+#pragma unroll
+            for (int b = 0; b < WTN; ++b) {
+                const int n = n0 + (wn * WTN + b) * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + (wm * WTM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    hmask[a][b][r] = g.H[m * g.ldh + n];
+                }
+            }
     }
     ABT_FETCH(0)
     ABT_PARK(0)
@@ -116,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     for (int k0 = 16; k0 < g.K; k0 += 16) {
         ABT_FETCH(k0)
         __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMA block (hipcc sinks it to save VGPRs)
-        abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
+        abt_compute<WTM, WTN, LDA, LDB>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
         __builtin_amdgcn_sched_barrier(0);
         ABT_PARK(buf ^ 1)
         __syncthreads();
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 #undef ABT_FETCH
 #undef ABT_PARK
-    abt_compute<WTM, WTN>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
+    abt_compute<WTM, WTN, LDA, LDB>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                     v += bias;
                 } else if (EPI == EPI_BWD_MASK) {
                     if (g.r1a) v = fmaf(g.r1a[m * g.r1a_ld], r1b, v);
-                    v = g.H[m * g.ldh + n] > 0.f ? v : g.alpha * v;
+                    v = hmask[a][b][r] > 0.f ? v : g.alpha * v;
                 } else {
                     if (g.accumulate) v += g.Out[m * g.ldo + n];
                 }
