@@ -21,7 +21,7 @@ struct GemmAbt {
     const float* Bt; int ldb;
     float* Out; int ldo;
     long long M;                // multiple of 128
-    int N, K;                   // N multiple of the column tile (128 wide / 32 narrow), K multiple of 16
+    int N, K;                   // N multiple of the column tile (128 wide / 32 narrow), K multiple of 32
     const float* bias;          // FWD_*: [N]
     const float* H; int ldh;    // BWD_MASK: stored activation of the layer whose pre-activation gradient is produced
     const float* r1a; int r1a_ld;   // BWD_MASK optional rank-1 term  r1a[m*r1a_ld] * r1b[n]

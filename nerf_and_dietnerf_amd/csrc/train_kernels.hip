@@ -30,25 +30,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // row each) spread over all 64 banks.  (A row-major tile read with ds_read_b128 measured 0.37 bank-conflict cycles
 // per busy cycle: SQ_LDS_BANK_CONFLICT, rocprofv3 --pmc.)
 
-// One k-step (16) of the workgroup tile: operands from one LDS buffer into the wave's MFMA tiles.
+// One k-step (kKT = 32) of the workgroup tile: operands from one LDS buffer into the wave's MFMA tiles.
+// A k-step of 32 makes every staged row a full 128-byte line of the row-major operand (64-byte half lines with a
+// 16-wide step held both gemm_abt variants at 2.5 TB/s of HBM traffic) and halves the barriers per FLOP.
+constexpr int kKT = 32;
+
 template <int WTM, int WTN, int LDA, int LDB>
 __device__ __forceinline__ void abt_compute(const float* As, const float* Bs, int a_row0, int b_row0, int li, int lh,
                                             f32x16 (&acc)[WTM][WTN]) {
-    float av[WTM][8], bv[WTN][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int h = 0; h < 2; ++h) {          // two halves of 8 MFMA steps: 16 operand registers live at a time
+        float av[WTM][8], bv[WTN][8];
 #pragma unroll
-        for (int a = 0; a < WTM; ++a) av[a][j] = As[(8 * lh + j) * LDA + a_row0 + a * 32 + li];
+        for (int j = 0; j < 8; ++j) {
 #pragma unroll
-        for (int b = 0; b < WTN; ++b) bv[b][j] = Bs[(8 * lh + j) * LDB + b_row0 + b * 32 + li];
+            for (int a = 0; a < WTM; ++a) av[a][j] = As[(16 * lh + 8 * h + j) * LDA + a_row0 + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < WTN; ++b) bv[b][j] = Bs[(16 * lh + 8 * h + j) * LDB + b_row0 + b * 32 + li];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int a = 0; a < WTM; ++a)
+#pragma unroll
+                for (int b = 0; b < WTN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int a = 0; a < WTM; ++a)
-#pragma unroll
-            for (int b = 0; b < WTN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
 }
 
 __device__ __forceinline__ void park4(float* tile, int ld, int k4, int row, const float4& v) {
@@ -58,27 +65,41 @@ __device__ __forceinline__ void park4(float* tile, int ld, int k4, int row, cons
     tile[(k4 + 3) * ld + row] = v.w;
 }
 
+#ifndef NERF_ABT_MAXW
+#define NERF_ABT_MAXW 4
+#endif
 template <int WTM, int WTN, int WVM, int WVN, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_abt_kernel(const GemmAbt g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NERF_ABT_MAXW))) void gemm_abt_kernel(const GemmAbt g) {
     constexpr int TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
-    constexpr int LDA = TM + 4, LDB = TN + 4;
+    // k-major tiles [32][rows + 2]: operand reads (consecutive lanes = consecutive rows, lane halves 16 k apart = 32
+    // banks apart) and the transposing stores (8 lanes x 4 dwords per row) are both bank-conflict free
+    constexpr int LDA = TM + 2, LDB = TN + 2;
     static_assert(WVM * WVN == 4 && TM == 128, "4 waves, 128 rows per workgroup");
-    static_assert(TN * 4 % 256 == 0 || TN * 4 < 256, "B tile: whole float4 rounds, or a single partial one");
-    __shared__ __attribute__((aligned(16))) float As[2][16 * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][16 * LDB];
+    static_assert(TN == 128 || TN == 32, "staging below: 4 float4 per thread (128 rows) or 1 (32 rows)");
+    __shared__ __attribute__((aligned(16))) float As[2][kKT * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kKT * LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
     const int li = lane & 31, lh = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
-    constexpr int A_F4 = TM * 4 / 256;                    // float4 per thread and k-step
-    constexpr int B_F4 = TN * 4 >= 256 ? TN * 4 / 256 : 1;
-    constexpr bool B_PARTIAL = TN * 4 < 256;              // narrow tile: only the first TN*4 threads stage B
-    const bool b_on = !B_PARTIAL || t < TN * 4;
-    // staging slots of this thread (fixed): float4 #(t + 256 i) of a [rows x 16] tile = row (t >> 2) + 64 i, k 4 (t & 3)
-    const int srow = t >> 2, sk4 = 4 * (t & 3);
+    // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the column tiles of one row
+    // tile get ids 8 apart, i.e. the same XCD back to back, so the second one finds the A rows in that L2.
+    const int n_tiles = g.N / TN;
+    const long long lin = blockIdx.x, grp = lin / (8 * n_tiles), rem = lin % (8 * n_tiles);
+    long long m_tile = grp * 8 + rem % 8;
+    int n_tile = (int)(rem / 8);
+    const long long m_tiles = g.M / TM;
+    if (grp * 8 + 8 > m_tiles) {          // ragged last group: plain order
+        const long long base = grp * 8 * n_tiles, r2 = lin - base, left = m_tiles - grp * 8;
+        m_tile = grp * 8 + r2 % left;
+        n_tile = (int)(r2 / left);
+    }
+    const long long m0 = m_tile * TM;
+    const int n0 = n_tile * TN;
+    constexpr bool B_WIDE = TN == 128;
+    // staging slots of this thread: float4 #(t + 256 i) of a [rows x 32] tile = row (t >> 3) + 32 i, k 4 (t & 7)
+    const int srow = t >> 3, sk4 = 4 * (t & 7);
     const float* ap = g.A + (m0 + srow) * g.lda + sk4;
-    const float* bp = g.Bt + (size_t)(n0 + (B_PARTIAL ? (srow % TN) : srow)) * g.ldb + sk4;
+    const float* bp = g.Bt + (size_t)(n0 + srow) * g.ldb + sk4;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -89,27 +110,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // (scalars, not arrays: hipcc otherwise parks small private arrays in LDS / scratch and waits on every load)
-    static_assert(A_F4 == 2 && (B_F4 == 1 || B_F4 == 2 || B_F4 == 4), "staging registers below are written out by hand");
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t a1 = (size_t)64 * g.lda, b1 = (size_t)64 * g.ldb;
-    float4 ra0, ra1, rb0 = z4, rb1 = z4, rb2 = z4, rb3 = z4;
+    const size_t a1 = (size_t)32 * g.lda, b1 = (size_t)32 * g.ldb;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1 = z4, rb2 = z4, rb3 = z4;
 #define ABT_FETCH(K0)                                                                      \
     ra0 = *reinterpret_cast<const float4*>(ap + (K0));                                     \
     ra1 = *reinterpret_cast<const float4*>(ap + a1 + (K0));                                \
-    if (b_on) rb0 = *reinterpret_cast<const float4*>(bp + (K0));                           \
-    if (B_F4 >= 2) rb1 = *reinterpret_cast<const float4*>(bp + b1 + (K0));                 \
-    if (B_F4 == 4) {                                                                       \
+    ra2 = *reinterpret_cast<const float4*>(ap + 2 * a1 + (K0));                            \
+    ra3 = *reinterpret_cast<const float4*>(ap + 3 * a1 + (K0));                            \
+    rb0 = *reinterpret_cast<const float4*>(bp + (K0));                                     \
+    if (B_WIDE) {                                                                          \
+        rb1 = *reinterpret_cast<const float4*>(bp + b1 + (K0));                            \
         rb2 = *reinterpret_cast<const float4*>(bp + 2 * b1 + (K0));                        \
         rb3 = *reinterpret_cast<const float4*>(bp + 3 * b1 + (K0));                        \
     }
 #define ABT_PARK(BUF)                                                                      \
     park4(As[BUF], LDA, sk4, srow, ra0);                                                   \
-    park4(As[BUF], LDA, sk4, srow + 64, ra1);                                              \
-    if (b_on) park4(Bs[BUF], LDB, sk4, srow, rb0);                                         \
-    if (B_F4 >= 2) park4(Bs[BUF], LDB, sk4, srow + 64, rb1);                               \
-    if (B_F4 == 4) {                                                                       \
-        park4(Bs[BUF], LDB, sk4, srow + 128, rb2);                                         \
-        park4(Bs[BUF], LDB, sk4, srow + 192, rb3);                                         \
+    park4(As[BUF], LDA, sk4, srow + 32, ra1);                                              \
+    park4(As[BUF], LDA, sk4, srow + 64, ra2);                                              \
+    park4(As[BUF], LDA, sk4, srow + 96, ra3);                                              \
+    park4(Bs[BUF], LDB, sk4, srow, rb0);                                                   \
+    if (B_WIDE) {                                                                          \
+        park4(Bs[BUF], LDB, sk4, srow + 32, rb1);                                          \
+        park4(Bs[BUF], LDB, sk4, srow + 64, rb2);                                          \
+        park4(Bs[BUF], LDB, sk4, srow + 96, rb3);                                          \
     }
     // data-gradient epilogue: the LeakyReLU' mask comes from the stored activation H.  Fetching it here, before the
     // k loop, hides the 64 scattered loads per lane behind the MFMAs (fetched in the epilogue they were the kernel's
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     __syncthreads();
     int buf = 0;
     // steady state: fetch k-step s+1 into registers, multiply k-step s out of LDS, park s+1 in the other buffer
-    for (int k0 = 16; k0 < g.K; k0 += 16) {
+    for (int k0 = kKT; k0 < g.K; k0 += kKT) {
         ABT_FETCH(k0)
         __builtin_amdgcn_sched_barrier(0);   // keep the fetch ahead of the MFMA block (hipcc sinks it to save VGPRs)
         abt_compute<WTM, WTN, LDA, LDB>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
@@ -178,11 +202,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 template <int EPI>
 static void launch_abt_epi(bool narrow, const GemmAbt& g, hipStream_t s) {
     if (narrow)
-        hipLaunchKernelGGL((gemm_abt_kernel<1, 1, 4, 1, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 32)),
-                           dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_abt_kernel<1, 1, 4, 1, EPI>), dim3((unsigned)((g.M / 128) * (g.N / 32))), dim3(256), 0,
+                           s, g);
     else     // (a 128x256 tile -- A read once, occupancy 2 -- measured 9 % slower than two 128x128 tiles at occupancy 3)
-        hipLaunchKernelGGL((gemm_abt_kernel<2, 2, 2, 2, EPI>), dim3((unsigned)(g.M / 128), (unsigned)(g.N / 128)),
-                           dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_abt_kernel<2, 2, 2, 2, EPI>), dim3((unsigned)((g.M / 128) * (g.N / 128))), dim3(256), 0,
+                           s, g);
 }
 
 void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s) {

@@ -17,4 +17,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BU
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_${mode}b -o b --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --precision $mode > /root/repo/gpurun_out/pmc_${mode}b.log 2>&1; echo "pmcB $mode rc $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_${mode}c -o c --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --precision $mode > /root/repo/gpurun_out/pmc_${mode}c.log 2>&1; echo "pmcC $mode rc $?"
 done
+PMCSET="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc $PMCSET -d /root/repo/gpurun_out/pmc_traina -o a --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > /root/repo/gpurun_out/pmc_traina.log 2>&1; echo "pmcA train rc $?"
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_trainb -o b --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > /root/repo/gpurun_out/pmc_trainb.log 2>&1; echo "pmcB train rc $?"
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_trainc -o c --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > /root/repo/gpurun_out/pmc_trainc.log 2>&1; echo "pmcC train rc $?"
 fi
