@@ -254,7 +254,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int kb = blockIdx.x * 128, nb = blockIdx.y * 128, split = blockIdx.z;
+    // 1-D grid; the tiles of one row slab get ids 8 apart (same XCD, back to back): the slab's A and G rows are then
+    // read from HBM once and served to the other tiles out of that XCD's L2.
+    const int kt_n = (g.Kp + 127) / 128, nt_n = (g.Nw + 127) / 128, T = kt_n * nt_n;
+    const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
+    int split = grp * 8 + rem % 8, tile = rem / 8;
+    if (grp * 8 + 8 > n_splits) {         // ragged last group: plain order
+        const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
+        split = grp * 8 + r2 % left;
+        tile = r2 / left;
+    }
+    const int kb = (tile % kt_n) * 128, nb = (tile / kt_n) * 128;
+    const bool first_ktile = tile % kt_n == 0;
     const long long ms = (long long)split * g.rows_per_split;
     const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
     // staging slots of this thread: float4 #(t + 256 i), i = 0, 1, of a [16 rows x 128 cols] tile
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float colsum = 0.f;
-    const bool do_colsum = blockIdx.x == 0 && t < 128;
+    const bool do_colsum = first_ktile && t < 128;
 
     if (ms < me) {      // uniform per workgroup
         const size_t a8 = (size_t)8 * g.lda, g8 = (size_t)8 * g.ldg;
@@ -323,8 +335,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s) {
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    hipLaunchKernelGGL(gemm_atb_kernel, dim3((unsigned)((g.Kp + 127) / 128), (unsigned)((g.Nw + 127) / 128), (unsigned)splits),
-                       dim3(256), 0, s, g);
+    const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
+    hipLaunchKernelGGL(gemm_atb_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------------
