@@ -214,8 +214,10 @@ def main():
             value = count * args.rehearse_world * args.steps / elapsed
         dtype = "f32" if args.precision == "fp32" else "f16x3"
         ach = (n_rows * FLOPS_PER_ROW) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-        traffic = None
+        traffic = None      # PMC figure of the N=1 launches (profiles/pmc_traffic.json); smaller slabs at N>1: not measured
         try:
+            if world > 1:
+                raise LookupError
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 traffic = json.load(f).get(dtype)
         except Exception:
