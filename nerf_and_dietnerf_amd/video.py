@@ -5,6 +5,10 @@
     histogram_equalize (grayscale branch)     src/UtilsCV.py:700-743        -> histogram_equalize_depth()
     get_l_to_r_c2w_matrices                   src/UtilsCV.py:407-425        -> get_l_to_r_c2w_matrices()
     get_sphere_matrix / get_sphere_matrices   src/UtilsCV.py:101-121,428-437 -> same names
+    interpolation_type_slerp_for_c2w, slerp_rotation_matrix, get_c2w_matrices_between_2_c2w_with_stretch
+                                              src/UtilsCV.py:175-247        -> same names (numpy quaternions)
+    get_path_c2w_matrices_to_render           src/ExecutionRun.py:421-437   -> get_path_c2w_matrices()
+    get_rotation_matrix_from_source_to_dest_mats   src/UtilsCV.py:683-697   -> same name
 
 Camera paths and the depth tone-mapping are O(#frames) host work in the reference and stay host-side
 numpy here; every frame's rays/MLP/compositing run on the GPU through `NeRF.render_image`.  Frames are
@@ -54,6 +58,87 @@ def get_l_to_r_c2w_matrices(total_frames: int) -> np.ndarray:
     mats = np.tile(np.eye(4, dtype=np.float32), (total_frames, 1, 1))
     mats[:, 0, 3] = np.linspace(0, 1, total_frames) * 2 - 1
     return mats
+
+
+# ---------------------------------------------------------------------------------------------
+# pose interpolation for the "path" video: slerp of the rotations, lerp of the positions
+# (the reference goes through tensorflow_graphics / numpy-quaternion; plain numpy here, quaternions as [x, y, z, w])
+# ---------------------------------------------------------------------------------------------
+def quaternion_from_rotation_matrix(m: np.ndarray) -> np.ndarray:
+    m = np.asarray(m, np.float64)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = 2.0 * np.sqrt(tr + 1.0)
+        q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = 2.0 * np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2])
+        q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = 2.0 * np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2])
+        q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+    else:
+        s = 2.0 * np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1])
+        q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+    return np.asarray(q, np.float64)
+
+
+def rotation_matrix_from_quaternion(q: np.ndarray) -> np.ndarray:
+    x, y, z, w = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def slerp_rotation_matrix(p0: np.ndarray, p1: np.ndarray, t: float) -> np.ndarray:
+    """Spherical linear interpolation of two unit quaternions along the shorter arc."""
+    cos_a = float(np.dot(p0, p1))
+    if cos_a < 0:
+        p1, cos_a = -p1, -cos_a
+    omega = np.arccos(min(cos_a, 1.0))
+    sin_omega = np.sin(omega)
+    if sin_omega < 1e-12:                              # identical rotations (the reference divides 0/0 here)
+        return np.array(p0, np.float64)
+    return np.sin((1.0 - t) * omega) / sin_omega * p0 + np.sin(t * omega) / sin_omega * p1
+
+
+def interpolation_type_slerp_for_c2w(c2w1: np.ndarray, c2w2: np.ndarray, alpha):
+    """Pose(s) between two camera-to-world matrices: slerp of the rotation, lerp of the position; ``alpha`` a float
+    or an array of floats in [0, 1] (-> one (4,4) float32 matrix, or a list of them)."""
+    def one(t: float) -> np.ndarray:
+        q = slerp_rotation_matrix(quaternion_from_rotation_matrix(c2w1[:3, :3]),
+                                  quaternion_from_rotation_matrix(c2w2[:3, :3]), float(t))
+        m = np.eye(4)
+        m[:3, :3] = rotation_matrix_from_quaternion(q)
+        m[:3, 3] = np.asarray(c2w1, np.float64)[:3, 3] * (1 - t) + np.asarray(c2w2, np.float64)[:3, 3] * t
+        return m.astype(np.float32)
+    alpha = np.asarray(alpha)
+    return [one(a) for a in alpha] if alpha.shape != () else one(alpha)
+
+
+def get_c2w_matrices_between_2_c2w_with_stretch(c2w1, c2w2, n_renders: int, stretch_knob: float = 1) -> list:
+    """``n_renders`` poses from c2w1 to c2w2, denser near c2w2 (the video slows down before it halts)."""
+    alpha = np.linspace(0, 1, n_renders)
+    stretched = alpha * (1 / (alpha + 1 + stretch_knob))
+    stretched = (stretched - stretched.min()) / (stretched.max() - stretched.min())
+    return interpolation_type_slerp_for_c2w(c2w1, c2w2, stretched)
+
+
+def get_path_c2w_matrices(camera_poses: np.ndarray, img_indices: Sequence[int], frames_per_leg: int) -> np.ndarray:
+    """Closed tour through the chosen dataset views (``video.img_indices_for_path_video`` of the YAML):
+    ``frames_per_leg`` = fps_render_video * 2 in the reference."""
+    c2ws = np.asarray(camera_poses)[list(img_indices)]
+    out = []
+    for a, b in zip(c2ws[:-1], c2ws[1:]):
+        out.extend(get_c2w_matrices_between_2_c2w_with_stretch(a, b, frames_per_leg))
+    out.extend(get_c2w_matrices_between_2_c2w_with_stretch(c2ws[-1], c2ws[0], frames_per_leg))
+    return np.asarray(out, dtype=np.float32)
+
+
+def get_rotation_matrix_from_source_to_dest_mats(source_mat: np.ndarray, dest_mat: np.ndarray) -> np.ndarray:
+    """(4,4) rotation taking ``source_mat`` to ``dest_mat``: q_dest * q_source^-1 = R_dest @ R_source^T."""
+    m = np.eye(4)
+    m[:3, :3] = np.asarray(dest_mat, np.float64)[:3, :3] @ np.asarray(source_mat, np.float64)[:3, :3].T
+    return m
 
 
 # ---------------------------------------------------------------------------------------------

@@ -92,3 +92,39 @@ def test_blender_loader_semantics(tmp_path):
     pa = N.poses_avg(cams.astype(np.float64))
     np.testing.assert_allclose(pa[:, :3], np.eye(3), atol=1e-6)
     np.testing.assert_allclose(pa[:, 3], 0.0, atol=1e-6)
+
+
+def test_path_video_pose_interpolation(golden_ckpt):
+    """Slerp/lerp pose interpolation of the path video: end points reproduced, rotations stay orthonormal, constant
+    angular speed in alpha, the 'stretch' packs more frames near the destination, closed tour through the views."""
+    import nerf_and_dietnerf_amd as N
+    from nerf_and_dietnerf_amd import video as V
+    a = N.get_sphere_matrix(1.0, -20, 10, 0).astype(np.float32)
+    b = N.get_sphere_matrix(1.0, 15, 80, 5).astype(np.float32)
+    m0, m1 = N.interpolation_type_slerp_for_c2w(a, b, 0.0), N.interpolation_type_slerp_for_c2w(a, b, 1.0)
+    np.testing.assert_allclose(m0, a, atol=2e-6)
+    np.testing.assert_allclose(m1, b, atol=2e-6)
+    mids = N.interpolation_type_slerp_for_c2w(a, b, np.linspace(0, 1, 9))
+    ang = []
+    for m in mids:
+        r = m[:3, :3].astype(np.float64)
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-5)
+        assert abs(np.linalg.det(r) - 1) < 1e-5
+        ang.append(np.arccos(np.clip((np.trace(a[:3, :3].astype(np.float64).T @ r) - 1) / 2, -1, 1)))
+    np.testing.assert_allclose(np.diff(ang), np.diff(ang)[0], rtol=2e-3, atol=1e-5)     # constant angular speed
+    np.testing.assert_allclose(mids[4][:3, 3], 0.5 * (a[:3, 3] + b[:3, 3]), atol=1e-6)   # positions: lerp
+    # quaternion round trip on every branch of the conversion
+    for deg in ((0, 0, 0), (170, 0, 0), (0, 170, 0), (0, 0, 170), (120, 120, 45)):
+        r = N.get_sphere_matrix(1.0, *deg)[:3, :3]
+        np.testing.assert_allclose(V.rotation_matrix_from_quaternion(V.quaternion_from_rotation_matrix(r)), r, atol=1e-12)
+    leg = N.get_c2w_matrices_between_2_c2w_with_stretch(a, b, 20)
+    steps = [np.linalg.norm(leg[i + 1][:3, 3] - leg[i][:3, 3]) for i in range(19)]
+    assert len(leg) == 20 and steps[0] > steps[-1] > 0                                  # slows down before the halt
+    poses = np.stack([N.get_sphere_matrix(1.0, 0, d, 0) for d in (0, 40, 90, 200)]).astype(np.float32)
+    tour = N.get_path_c2w_matrices(poses, [0, 1, 3], 10)
+    assert tour.shape == (30, 4, 4) and tour.dtype == np.float32
+    np.testing.assert_allclose(tour[0], poses[0], atol=2e-6)
+    np.testing.assert_allclose(tour[9], poses[1], atol=2e-6)
+    np.testing.assert_allclose(tour[29], poses[0], atol=2e-6)                            # closed
+    rot = N.get_rotation_matrix_from_source_to_dest_mats(a[:3, :3], b[:3, :3])
+    np.testing.assert_allclose(rot[:3, :3] @ a[:3, :3].astype(np.float64), b[:3, :3], atol=1e-6)
