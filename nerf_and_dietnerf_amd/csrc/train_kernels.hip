@@ -21,6 +21,12 @@ namespace nerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// acc += a (x) b on v_mfma_f32_32x32x2_f32.  (Forcing the accumulators into AGPRs with an inline-asm MFMA -- hipcc keeps
+// them in arch VGPRs here -- measured 2 % slower: the volatile asm pins the schedule.)
+__device__ __forceinline__ void mfma_acc(f32x16& acc, float a, float b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm_abt
 // ------------------------------------------------------------------------------------------------
@@ -54,7 +60,7 @@ __device__ __forceinline__ void abt_compute(const float* As, const float* Bs, in
             for (int a = 0; a < WTM; ++a)
 #pragma unroll
                 for (int b = 0; b < WTN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+                    mfma_acc(acc[a][b], av[a][j], bv[b][j]);
     }
 }
 
@@ -245,7 +251,7 @@ __device__ __forceinline__ void atb_compute(const float* As, const float* Gs, in
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+                mfma_acc(acc[a][b], av[a][j], bv[b][j]);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_atb_kernel(const GemmAtb g) {
