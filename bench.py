@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOPS_PER_ROW = 2 * 512152          # GEMM MACs per sample x 2
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak per dtype fed to MFMA
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak per dtype fed to MFMA
 H = W = 256
 SC, SF = 64, 128
 NEAR, FAR, FOV = 2.0 / 3.0, 5.0 / 3.0, 0.6911112
@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16"],
                     help="arithmetic of the 256-wide contractions: f16x3 = 3-pass split-fp16 MFMA with fp32 accumulate "
                          "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,6 +179,27 @@ def main():
                  "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel", "achieved": a32, "peak": PEAK_TFLOPS["f32"],
                               "unit": "TFLOP/s", "frac": a32 / PEAK_TFLOPS["f32"]}}
 
+    # the single-pass fp16 mode (the reference's production mixed_float16 numerics class; BASELINE configs[4] "fp16 MLP")
+    fp16_mode = None
+    if world == 1 and args.precision == "f16x3" and args.rehearse_world <= 1:
+        model.ctx.set_precision("f16")
+        step(0)
+        sync()
+        model.ctx.enable_timing(True)
+        t3 = time.perf_counter()
+        for i in range(5):
+            step(i)
+        sync()
+        e16 = time.perf_counter() - t3
+        ms16, nl16, rows16 = model.ctx.read_timing()
+        model.ctx.enable_timing(False)
+        model.ctx.set_precision("f16x3")
+        a16 = rows16 * FLOPS_PER_ROW / (ms16 * 1e-3) / 1e12
+        fp16_mode = {"dtype": "f16 (single pass, fp16 activations between layers: mixed_float16-class, not the fp32 parity mode)",
+                     "value": total * 5 / e16, "unit": "rays/s", "steps": 5,
+                     "roofline": {"bound": "mfma", "kernel": "mlp_f16_kernel", "achieved": a16, "peak": PEAK_TFLOPS["f16"],
+                                  "unit": "TFLOP/s", "frac": a16 / PEAK_TFLOPS["f16"]}}
+
     # the training step on the reference's batch, timed briefly beside the headline (N=1 only)
     train = None
     if world == 1 and args.rehearse_world <= 1 and not args.no_train:
@@ -212,7 +233,7 @@ def main():
         value = total * args.steps / elapsed
         if args.rehearse_world > 1 and world == 1:
             value = count * args.rehearse_world * args.steps / elapsed
-        dtype = "f32" if args.precision == "fp32" else "f16x3"
+        dtype = {"fp32": "f32", "f16x3": "f16x3", "f16": "f16"}[args.precision]
         ach = (n_rows * FLOPS_PER_ROW) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         traffic = None      # PMC figure of the N=1 launches (profiles/pmc_traffic.json); smaller slabs at N>1: not measured
         try:
@@ -227,21 +248,24 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if dtype == "f32" else "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
+            "dtype": {"f32": "f32", "f16x3": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
+                      "f16": "f16 (single pass, f32 accumulate, fp16 activations: mixed_float16-class results, NOT the fp32 parity mode)"}[dtype],
             "data": "synthetic (random-init Glorot weights, sphere pose, "
                                                           "on-device Philox draws)",
-            "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine (BASELINE configs[1]); contractions in " + ("exact fp32 MFMA" if dtype == "f32" else "3-pass split-fp16 MFMA, fp32 accumulate"),
+            "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine (BASELINE configs[1]); contractions in " + {"f32": "exact fp32 MFMA", "f16x3": "3-pass split-fp16 MFMA, fp32 accumulate", "f16": "1-pass fp16 MFMA, fp32 accumulate"}[dtype],
                        "rays_per_step": total, "mlp_rows_per_ray": SC + SC + SF,
                        "parallelism": f"ray-sharded x{world}, one all-gather of RGB per frame"},
-            "roofline": {"bound": "mfma", "kernel": ("mlp_fp32_kernel" if dtype == "f32" else "mlp_f16x3_kernel") + " (fused PE + 11-layer MLP)",
+            "roofline": {"bound": "mfma", "kernel": {"f32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel", "f16": "mlp_f16_kernel"}[dtype] + " (fused PE + 11-layer MLP)",
                          "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[dtype], "frac_vs_fp32_matrix_peak": ach / PEAK_TFLOPS["f32"],
-                         "mfma_passes_per_product": 1 if dtype == "f32" else 3, "traffic": traffic,
+                         "mfma_passes_per_product": 3 if dtype == "f16x3" else 1, "traffic": traffic,
                          "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),
                          "flops_per_row": FLOPS_PER_ROW, "rows": int(n_rows)},
         }
         if other is not None:
             out["fp32_exact_mode"] = other
+        if fp16_mode is not None:
+            out["fp16_single_pass_mode"] = fp16_mode
         if train is not None:
             out["training"] = train
         if world == 1 and not args.no_cpu_baseline:

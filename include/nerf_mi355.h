@@ -36,7 +36,10 @@ enum { NERF_MEM_HOST = 0, NERF_MEM_DEVICE = 1 };
 /* arithmetic of the 256-wide contractions; everything else is always fp32 */
 enum {
     NERF_PRECISION_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode)      */
-    NERF_PRECISION_F16X3 = 1   /* 3-pass split-fp16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+    NERF_PRECISION_F16X3 = 1,  /* 3-pass split-fp16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+    NERF_PRECISION_F16 = 2     /* 1-pass fp16 MFMA, fp32 accumulate, activations rounded to fp16 between layers: the
+                                  numerics class of the reference's production policy (mixed_float16,
+                                  src/ExecutionRun.py:220-221); NOT the fp32 parity mode */
 };
 
 /* Network + frustum description: the 9 net/render keys of src/ConfigurationKeys.py:64-111. */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NERF_MI355_LIB") or os.path.join(_HERE, "lib", "libne
 
 NERF_NET_COARSE, NERF_NET_FINE = 0, 1
 NERF_MEM_HOST, NERF_MEM_DEVICE = 0, 1
-NERF_PRECISION_FP32, NERF_PRECISION_F16X3 = 0, 1
+NERF_PRECISION_FP32, NERF_PRECISION_F16X3, NERF_PRECISION_F16 = 0, 1, 2
 NERF_ABI_VERSION = 1
 
 

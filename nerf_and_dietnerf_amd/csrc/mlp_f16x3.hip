@@ -87,7 +87,9 @@ __device__ __forceinline__ void split_trunc(float y, float& hi_f, float& lo_f) {
 // previous layer's last tile is finished during this layer's first tile), so no epilogue is exposed.
 //   fragments of the layer input live in xh/xl[16]; outputs of tiles 0..6 go to nh/nl and are copied
 //   back as the last tile's chain retires the k-steps that read them; tile 7 lands in xh/xl[14..15].
-template <int BODY, bool PENDING>
+// FAST = single-pass fp16 mode (NERF_PRECISION_F16: the reference's production mixed_float16 numerics): only the
+// hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
+template <int BODY, bool PENDING, bool FAST>
 __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
                                              float alpha, f32x16 (&accs)[4],
                                              frag4 (&xh)[16], frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14],
@@ -143,12 +145,18 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         constexpr int n = 2 * ut + (r >> 3), e = r & 7;
-        float h0, l0, h1, l1;
-        split_trunc(y0, h0, l0);
-        split_trunc(y1, h1, l1);
-        const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);   // whole-register writes
-        if constexpr (decltype(dest_sel)::value) { xh[n][e >> 1] = ph; xl[n][e >> 1] = pl; }
-        else { nh[n][e >> 1] = ph; nl[n][e >> 1] = pl; }
+        if constexpr (FAST) {
+            const uint32_t ph = pack_h2(y0, y1);                          // round to fp16, no lo part
+            if constexpr (decltype(dest_sel)::value) xh[n][e >> 1] = ph;
+            else nh[n][e >> 1] = ph;
+        } else {
+            float h0, l0, h1, l1;
+            split_trunc(y0, h0, l0);
+            split_trunc(y1, h1, l1);
+            const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);   // whole-register writes
+            if constexpr (decltype(dest_sel)::value) { xh[n][e >> 1] = ph; xl[n][e >> 1] = pl; }
+            else { nh[n][e >> 1] = ph; nl[n][e >> 1] = pl; }
+        }
     };
 
     float ycarry = 0.f;
@@ -212,8 +220,10 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             constexpr bool kPrevS = (u > 0) && BODY != BODY_PE && NSTEP >= 16 && n < 16;
             constexpr int et = kPend ? 7 : (u > 0 ? u - 1 : 0);
             constexpr bool kXc = BODY == BODY_LAST && kPrevS;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            if constexpr (!FAST) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
             if constexpr (kPend) {
                 constexpr int er = 2 * n;
@@ -261,10 +271,16 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     p.ck += 1;
 }
 
-// fp32 values -> fp16 hi / lo fragments
+// fp32 values -> fp16 hi / lo fragments (FAST: hi = the value rounded to fp16, no lo)
+template <bool FAST>
 __device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
+        if constexpr (FAST) {
+            hi[e >> 1] = pack_h2(v[e], v[e + 1]);
+            lo[e >> 1] = 0u;
+            continue;
+        }
         float h0, l0, h1, l1;
         split_trunc(v[e], h0, l0);
         split_trunc(v[e + 1], h1, l1);
@@ -273,7 +289,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
+template <bool FAST>
+__device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
             float t8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) t8[e] = pv[n * 8 + e];
-            split8(t8, peh[n], pel[n]);
+            split8<FAST>(t8, peh[n], pel[n]);
         }
         float dv[16];
 #pragma unroll
@@ -369,23 +386,23 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
             float t8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) t8[e] = dv[n * 8 + e];
-            split8(t8, dh[n], dl[n]);
+            split8<FAST>(t8, dh[n], dl[n]);
         }
 
         STAMP(t1); acc_t[0] += t1 - t0;
-        layer_body_h<BODY_PE, false>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        layer_body_h<BODY_PE, false, FAST>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             if (l == 4) {
-                layer_body_h<BODY_SKIP, true>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_SKIP, true, FAST>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
             } else {
-                layer_body_h<BODY_HID, true>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_HID, true, FAST>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
-        layer_body_h<BODY_LAST, true>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        layer_body_h<BODY_LAST, true, FAST>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t1); acc_t[4] += t1 - t0;
 
         // rgb head (128 -> 3) on the VALU in fp32
@@ -427,11 +444,15 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream) {
+__global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) { mlp_f16_body<false>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16_kernel(const MlpArgs a) { mlp_f16_body<true>(a); }
+
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 127) / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    hipLaunchKernelGGL(mlp_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    if (single_pass) hipLaunchKernelGGL(mlp_f16_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    else hipLaunchKernelGGL(mlp_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
 #ifdef NERF_STAMPS
@@ -443,6 +464,8 @@ extern "C" void nerf_debug_read_stamps_h(unsigned long long* out) {
 
 void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 

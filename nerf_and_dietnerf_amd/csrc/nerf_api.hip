@@ -100,8 +100,10 @@ int check_cfg(const nerf_config* cfg) {
         cfg->last_hidden_dim != kLast)
         return fail("fused kernel is specialised for Lx=%d Ld=%d hidden=%d last=%d (got %d %d %d %d)", kLx, kLd,
                     kHidden, kLast, cfg->n_pos_enc_xyz, cfg->n_pos_enc_dir, cfg->hidden_dim, cfg->last_hidden_dim);
-    if (cfg->precision != NERF_PRECISION_FP32 && cfg->precision != NERF_PRECISION_F16X3)
-        return fail("unknown precision %d (NERF_PRECISION_FP32 = 0, NERF_PRECISION_F16X3 = 1)", cfg->precision);
+    if (cfg->precision != NERF_PRECISION_FP32 && cfg->precision != NERF_PRECISION_F16X3 &&
+        cfg->precision != NERF_PRECISION_F16)
+        return fail("unknown precision %d (NERF_PRECISION_FP32 = 0, NERF_PRECISION_F16X3 = 1, NERF_PRECISION_F16 = 2)",
+                    cfg->precision);
     return 0;
 }
 
@@ -115,7 +117,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         c->timed_rows += c->timing ? M : 0;
         return layerwise_forward(c, which, in_a, in_b, z, raw, M, S, mode);
     }
-    const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3;
+    const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3 || c->cfg.precision == NERF_PRECISION_F16;
     MlpArgs a;
     a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
     a.wconst = f16 ? c->net[which].cst_h : c->net[which].cst;
@@ -135,7 +137,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         c->timed_rows += M;
         HIP_OK(hipEventRecord(e0, c->stream));
     }
-    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream);
+    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16);
     else launch_mlp_fp32(a, c->num_cus, c->stream);
     if (c->timing) HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipGetLastError());
@@ -308,7 +310,7 @@ int nerf_ctx_set_bounds(nerf_ctx* c, float near_b, float far_b) {
 
 int nerf_ctx_set_precision(nerf_ctx* c, int precision) {
     if (!c) return fail("ctx is NULL");
-    if (precision != NERF_PRECISION_FP32 && precision != NERF_PRECISION_F16X3)
+    if (precision != NERF_PRECISION_FP32 && precision != NERF_PRECISION_F16X3 && precision != NERF_PRECISION_F16)
         return fail("unknown precision %d", precision);
     if (c->cfg.n_angles == 0 && precision != NERF_PRECISION_FP32)
         return fail("the xyz-only network (n_angles_for_model=0) runs on the layer-wise fp32 path: use NERF_PRECISION_FP32");

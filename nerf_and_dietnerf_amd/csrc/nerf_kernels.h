@@ -74,7 +74,7 @@ void mlp_fp32_set_attributes();
 void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
 
 // mlp_f16x3.hip
-void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream);
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);   // single_pass: hi*hi only
 void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 

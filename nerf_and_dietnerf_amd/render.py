@@ -39,7 +39,7 @@ N_RAYS_IN_BATCH_TRAIN = "n_rays_in_batch_train"
 N_COORDINATES = 3
 N_COLOR_CHANNELS = 3
 
-_PRECISIONS = {"fp32": NERF_PRECISION_FP32, "f16x3": NERF_PRECISION_F16X3}
+_PRECISIONS = {"fp32": NERF_PRECISION_FP32, "f16x3": NERF_PRECISION_F16X3, "f16": _lib.NERF_PRECISION_F16}
 
 
 # --------------------------------------------------------------------------------------------

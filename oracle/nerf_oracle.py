@@ -314,6 +314,28 @@ def mlp_forward(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.nda
     return np.concatenate([rgb, sigma], axis=-1).astype(F32)  # :339
 
 
+def mlp_forward_fp16(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.ndarray,
+                     dir_enc: np.ndarray, alpha: float = 0.05) -> np.ndarray:
+    """Emulation of the library's NERF_PRECISION_F16 mode (the numerics class of the reference's production
+    mixed_float16 policy, src/ExecutionRun.py:220-221; not TensorFlow's exact op order): operands of every
+    256-wide contraction -- weights and layer inputs -- rounded to fp16 (RNE), products accumulated in fp32 on top of
+    the fp32 bias, LeakyReLU in fp32, activations rounded to fp16 between layers; the 128 -> 3 rgb head in fp32 on
+    the unrounded last hidden layer."""
+    q = lambda a: np.asarray(a, F32).astype(np.float16).astype(F32)
+    xq, dq = q(xyz_enc), q(dir_enc)
+    h = q(leaky_relu(xq @ q(layers[0][0]) + layers[0][1], alpha))
+    for k, b in layers[1:4]:
+        h = q(leaky_relu(h @ q(k) + b, alpha))
+    h = q(leaky_relu(np.concatenate([xq, h], axis=-1) @ q(layers[4][0]) + layers[4][1], alpha))
+    for k, b in layers[5:8]:
+        h = q(leaky_relu(h @ q(k) + b, alpha))
+    hd = np.concatenate([h, dq], axis=-1)
+    h8 = leaky_relu(hd @ q(layers[8][0]) + layers[8][1], alpha)          # stays fp32 for the VALU head
+    rgb = h8 @ layers[9][0] + layers[9][1]
+    sigma = hd @ q(layers[10][0]) + layers[10][1]
+    return np.concatenate([rgb, sigma], axis=-1).astype(F32)
+
+
 def model_predict(layers, xyz: np.ndarray, view_dirs: np.ndarray, n_pos_enc_xyz: int = 5,
                   n_pos_enc_dir: int = 4, alpha: float = 0.05, chunk: int = 1 << 18) -> np.ndarray:
     """src/UtilsNeuralRadianceField.py:214-234 (chunked only to bound host memory)."""

@@ -616,3 +616,38 @@ def test_xyz_only_network(oracle):
     with pytest.raises(RuntimeError, match="layer-wise fp32 path"):
         ctx.set_precision("f16x3")
     ctx.close()
+
+
+def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):
+    """NERF_PRECISION_F16: one fp16 MFMA pass per product, activations rounded to fp16 between layers -- the numerics
+    class of the reference's production policy (mixed_float16), config 5 of BASELINE.json ("fp16 MLP").  Checked
+    (a) against an emulation of exactly that arithmetic (oracle.mlp_forward_fp16) on raw network outputs,
+    (b) against the fp32 oracle at fp16-class tolerance on final RGB, (c) at the recorded-PSNR pin."""
+    import nerf_and_dietnerf_amd as N
+    coarse, fine = nets
+    ctx = nerf.ctx
+    ctx.set_precision("f16")
+    try:
+        rng = np.random.default_rng(12)
+        xyz = rng.uniform(-1.2, 1.2, (4096, 3)).astype(np.float32)
+        dirs = rng.uniform(-1, 1, (4096, 3)).astype(np.float32)
+        raw = ctx.model_predict(0, xyz, dirs)
+        emu = oracle.mlp_forward_fp16(coarse, oracle.positional_encoding_for_xyz(xyz, 5),
+                                      oracle.positional_encoding_for_views(dirs, 4))
+        ref = oracle.model_predict(coarse, xyz, dirs)
+        scale = max(1.0, float(np.abs(ref).max()))
+        err_emu, err_f32 = float(np.abs(raw - emu).max()) / scale, float(np.abs(raw - ref).max()) / scale
+        assert err_emu <= 2e-3, err_emu                      # same arithmetic up to fp32 summation order / RNE ties
+        assert err_f32 <= 5e-2 and err_emu < err_f32         # and visibly fp16-class, not fp32-class
+        o, d = golden_vec["rays_orig"], golden_vec["rays_dirs"]
+        uc, uf = golden_vec["u_coarse"], golden_vec["u_fine"]
+        out = ctx.render(o, d, uc.shape[1], uf.shape[1], uc, uf)
+        assert np.abs(out[0] - golden_vec["rgb"]).max() <= 3e-2
+        # the recorded PSNRs were produced under mixed_float16: the pin holds in this mode too
+        img = ctx.render_image(golden_ckpt["c2w_test"], float(golden_ckpt["fov"]), 50, 50, 4096, 64, 128, seed=3)[0]
+        tgt = golden_ckpt["img_test"].astype(np.float32) / 255.0
+        psnr = -10 * np.log10(np.mean((img - tgt) ** 2))
+        assert abs(psnr - float(golden_ckpt["recorded_psnr_test"])) <= 0.5, psnr
+        assert ctx.read_nonfinite() == 0
+    finally:
+        ctx.set_precision("fp32")
