@@ -61,6 +61,13 @@ constexpr int kHChunksSkip = (8 * kHQpuSkip + kHCQ - 1) / kHCQ;      // 10
 constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + kHCQ - 1) / kHCQ;   // 6
 constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 66
 static_assert(kHRing * kHChunkBytes == kRingBytes, "fp16 ring must fill the shared LDS carve");
+// single-pass mode: its own stream with the hi fragments only (one quad per k-step)
+constexpr int kFChunksPE = (8 * kHStepsPE + kHCQ - 1) / kHCQ;                          // 1
+constexpr int kFChunksHid = (8 * kHStepsHid) / kHCQ;                                   // 4
+constexpr int kFChunksSkip = (8 * (kHStepsPE + kHStepsHid) + kHCQ - 1) / kHCQ;         // 5
+constexpr int kFChunksLast = (kHTilesLast * (kHStepsHid + kHStepsDir) + kHCQ - 1) / kHCQ;   // 3
+constexpr int kFStreamChunks = kFChunksPE + 6 * kFChunksHid + kFChunksSkip + kFChunksLast;  // 33
+static_assert(kFStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16Hi, "hi-only stream size mismatch");
 // constant region (floats)
 constexpr int kHConstBias = 0;        // 8 x 256
 constexpr int kHConstBias8 = 2048;    // 128
@@ -98,7 +105,8 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     constexpr int NU = BODY == BODY_LAST ? kHTilesLast : 8;
     constexpr int NSTEP = BODY == BODY_PE ? kHStepsPE : BODY == BODY_HID ? kHStepsHid
                           : BODY == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
-    constexpr int QPU = 2 * NSTEP;
+    constexpr int TPS = FAST ? 1 : 2;        // quads (A fragments) per k-step: hi [, lo]
+    constexpr int QPU = TPS * NSTEP;
     constexpr int NQ = NU * QPU;
     // A fragments are fetched kPf quads (2 k-steps = 6 MFMAs = 192 cycles) ahead of their MFMAs.  The
     // ds_read is inline asm with a hand-counted s_waitcnt: left to itself hipcc sinks the reads next to
@@ -109,7 +117,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
 #ifndef NERF_KPF
 #define NERF_KPF 4
 #endif
-    constexpr int kPf = NERF_KPF;
+    constexpr int kPf = FAST ? 8 : NERF_KPF;   // single-pass: a quad is consumed every 32 cycles, look further ahead
     f32x4 pf[kPf];
     const int ck0 = p.ck;   // chunk of quad 0 of this body; quad Q lives in chunk ck0 + Q/16
     uint32_t rdbase[2];     // LDS address of the ring slot of an even / odd chunk (refreshed as chunks retire)
@@ -170,9 +178,9 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             f32x4 araw[2];
-            static_for<0, 2>([&](auto tc) {
+            static_for<0, TPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                constexpr int Q = u * QPU + 2 * n + t;
+                constexpr int Q = u * QPU + TPS * n + t;
                 constexpr int left = NQ - Q;
                 (void)left;
                 constexpr int qc = Q % kHCQ;        // position inside the chunk
@@ -201,7 +209,8 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 }
             });
             const h8 a_hi = __builtin_bit_cast(h8, araw[0]);
-            const h8 a_lo = __builtin_bit_cast(h8, araw[1]);
+            const h8 a_lo = __builtin_bit_cast(h8, araw[FAST ? 0 : 1]);
+            (void)a_lo;
             frag4 bh_, bl_;
             if constexpr (BODY == BODY_PE) { bh_ = peh[n]; bl_ = pel[n]; }
             else if constexpr (BODY == BODY_HID) { bh_ = xh[n]; bl_ = xl[n]; }
@@ -309,7 +318,7 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = kHStreamChunks;
+    p.n_chunks = FAST ? kFStreamChunks : kHStreamChunks;
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
@@ -522,7 +531,7 @@ int h_dir_row(int v, int h, int n_angles) {   // slot v (0..15) -> row of the di
 struct HLayer { const float* k; const float* b; int in, out; };
 }  // namespace
 
-void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out) {
+static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_out, float* const_out, bool hi_only) {
     const int kd = 256 + 8 * (n_angles + 1);
     const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
                                {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
@@ -533,7 +542,7 @@ void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float
         L[i].k = blob + off; off += (size_t)L[i].in * L[i].out;
         L[i].b = blob + off; off += L[i].out;
     }
-    memset(stream_out, 0, kStreamBytesF16);
+    memset(stream_out, 0, hi_only ? kStreamBytesF16Hi : kStreamBytesF16);
     memset(const_out, 0, kConstBytes);
     uint16_t* base = reinterpret_cast<uint16_t*>(stream_out);
     size_t chunk = 0;
@@ -564,11 +573,15 @@ void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float
                         }
                         const uint16_t hi = f32_to_f16(w);
                         const uint16_t lo = f32_to_f16(w - f16_to_f32(hi));
-                        const size_t q = (size_t)(u * NSTEP + n) * 2;
-                        b0[(q + 0) * (kQuadBytes / 2) + lane * 8 + e] = hi;
-                        b0[(q + 1) * (kQuadBytes / 2) + lane * 8 + e] = lo;
+                        if (hi_only) {
+                            b0[(size_t)(u * NSTEP + n) * (kQuadBytes / 2) + lane * 8 + e] = hi;
+                        } else {
+                            const size_t q = (size_t)(u * NSTEP + n) * 2;
+                            b0[(q + 0) * (kQuadBytes / 2) + lane * 8 + e] = hi;
+                            b0[(q + 1) * (kQuadBytes / 2) + lane * 8 + e] = lo;
+                        }
                     }
-        chunk += (NU * NSTEP * 2 + kHCQ - 1) / kHCQ;
+        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kHCQ - 1) / kHCQ;
     };
     emit_body(0, BODY_PE);
     for (int l = 1; l <= 3; ++l) emit_body(l, BODY_HID);
@@ -582,6 +595,13 @@ void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float
     for (int c = 0; c < 3; ++c)
         for (int f = 0; f < 128; ++f) const_out[kHConstWrgb + c * 128 + f] = L[9].k[f * 3 + c];
     for (int c = 0; c < 3; ++c) const_out[kHConstBHead + c] = L[9].b[c];
+}
+
+void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out) {
+    pack_weights_f16_impl(blob, n_angles, stream_out, const_out, false);
+}
+void pack_weights_f16(const float* blob, int n_angles, void* stream_out, float* const_out) {
+    pack_weights_f16_impl(blob, n_angles, stream_out, const_out, true);
 }
 
 }  // namespace nerf

@@ -80,6 +80,10 @@ int upload_packed_weights(nerf_ctx* c, int which, const float* blob) {
     if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
     HIP_OK(hipMemcpy(n.stream_h, sth.data(), kStreamBytesF16, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(n.cst_h, csh.data(), kConstBytes, hipMemcpyHostToDevice));
+    std::vector<uint16_t> sth1(kStreamBytesF16Hi / 2);
+    pack_weights_f16(blob, c->cfg.n_angles, sth1.data(), csh.data());       // same constants as the 3-pass stream
+    if (!n.stream_h1) HIP_OK(hipMalloc((void**)&n.stream_h1, kStreamBytesF16Hi));
+    HIP_OK(hipMemcpy(n.stream_h1, sth1.data(), kStreamBytesF16Hi, hipMemcpyHostToDevice));
     const size_t nf = nerf_blob_size(&c->cfg);
     if (n.host_blob.data() != blob) n.host_blob.assign(blob, blob + nf);
     n.loaded = true;
@@ -119,7 +123,8 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
     }
     const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3 || c->cfg.precision == NERF_PRECISION_F16;
     MlpArgs a;
-    a.wstream = f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
+    a.wstream = c->cfg.precision == NERF_PRECISION_F16 ? (const float*)c->net[which].stream_h1
+                : f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
     a.wconst = f16 ? c->net[which].cst_h : c->net[which].cst;
     a.in_a = in_a; a.in_b = in_b; a.z = z; a.raw = raw; a.M = M; a.S = S; a.mode = mode;
     a.nonfinite = c->nonfinite;
@@ -280,6 +285,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         if (n.stream) (void)hipFree(n.stream);
         if (n.cst) (void)hipFree(n.cst);
         if (n.stream_h) (void)hipFree(n.stream_h);
+        if (n.stream_h1) (void)hipFree(n.stream_h1);
         if (n.cst_h) (void)hipFree(n.cst_h);
     }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

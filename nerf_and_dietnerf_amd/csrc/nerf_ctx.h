@@ -29,6 +29,7 @@ struct NetWeights {
     float* stream = nullptr;     // kStreamBytes      (fp32 MFMA operand stream)
     float* cst = nullptr;        // kConstBytes
     void* stream_h = nullptr;    // kStreamBytesF16   (fp16 hi/lo fragment stream)
+    void* stream_h1 = nullptr;   // kStreamBytesF16Hi (fp16 hi-only stream of the single-pass mode)
     float* cst_h = nullptr;      // kConstBytes
     bool loaded = false;
     std::vector<float> host_blob;   // last blob handed to nerf_load_weights (Keras order): seed of the trainer

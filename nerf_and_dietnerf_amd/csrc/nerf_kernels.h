@@ -37,6 +37,7 @@ constexpr int kChunksLast = (4 * kQpuLast + 15) / 16;  // 9
 constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksLast;  // 127
 constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
 constexpr size_t kStreamBytesF16 = size_t(66) * 32 * kQuadBytes;   // f16x3 stream: 66 chunks of 32 KiB (mlp_f16x3.hip)
+constexpr size_t kStreamBytesF16Hi = size_t(33) * 32 * kQuadBytes; // single-pass fp16 stream: hi fragments only
 
 // ---- constant region (biases + head weights), floats ----
 constexpr int kConstBias = 0;                       // 8 x 256 hidden-layer biases (layers 0..7)
@@ -77,6 +78,7 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStr
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);   // single_pass: hi*hi only
 void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
+void pack_weights_f16(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16Hi*/, float* const_out /*kConstFloats*/);
 
 // aux_kernels.hip
 void launch_raygen(const float c2w_host[16], float fov, int H, int W,
