@@ -117,7 +117,10 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
 #ifndef NERF_KPF
 #define NERF_KPF 4
 #endif
-    constexpr int kPf = FAST ? 8 : NERF_KPF;   // single-pass: a quad is consumed every 32 cycles, look further ahead
+#ifndef NERF_KPF_FAST
+#define NERF_KPF_FAST 8
+#endif
+    constexpr int kPf = FAST ? NERF_KPF_FAST : NERF_KPF;   // single-pass: a quad is consumed every 32 cycles, look further ahead
     f32x4 pf[kPf];
     const int ck0 = p.ck;   // chunk of quad 0 of this body; quad Q lives in chunk ck0 + Q/16
     uint32_t rdbase[2];     // LDS address of the ring slot of an even / odd chunk (refreshed as chunks retire)
