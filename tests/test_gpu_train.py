@@ -393,3 +393,32 @@ def test_save_weights_after_training(oracle, golden_ckpt, tmp_path):
     np.testing.assert_array_equal(ra, rb)
     assert np.abs(a.get_weights()[0] - p["bc"]).max() > 1e-4
     a.ctx.close(); b.ctx.close()
+
+
+@pytest.mark.parametrize("n,sc,sf", [(1, 2, 1), (3, 2, 256), (130, 5, 3)])
+def test_train_edge_shapes_and_transparent_scene(oracle, golden_ckpt, n, sc, sf):
+    """Smallest legal shapes (1 ray, 2 coarse samples, 1 fine sample), the largest fine count, a batch that is not a
+    multiple of anything -- and a fully transparent coarse network (sigma = 0 everywhere: all-zero weights feed the
+    sampler, every cdf bin hits the 1e-5 clamp): loss equals the oracle's, gradients are finite and close."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt, n=max(n, 2), sc=sc, sf=sf, seed=n)
+    o, d, tgt, u_c, u_f = (p[k][:n] for k in ("o", "d", "tgt", "u_c", "u_f"))
+    for transparent in (False, True):
+        bc = p["bc"].copy()
+        if transparent:
+            bc[-(256 + 24 + 1):] = 0.0          # sigma head kernel ...
+            bc[-1] = -5.0                       # ... and a negative bias: relu -> sigma = 0
+        ctx = _ctx(dict(p, bc=bc))
+        ctx.train_begin(5e-4)
+        m, gc, gf = ctx.train_gradients(o, d, tgt, sc, sf, u_c, u_f)
+        r = T.train_gradients(bc, p["bf"], o, d, tgt, p["near"], p["far"], u_c, u_f)
+        assert np.isfinite(gc).all() and np.isfinite(gf).all() and np.isfinite(m["loss"])
+        assert abs(m["loss"] - r["loss"]) <= 5e-6 * r["loss"] + 1e-7
+        assert _relerr(gf, r["grad_fine"]) <= 5e-2
+        if np.abs(r["grad_coarse"]).max() > 1e-12:
+            assert _relerr(gc, r["grad_coarse"]) <= 5e-2
+        else:
+            assert np.abs(gc).max() <= 1e-9
+        first = ctx.train_step(o, d, tgt, sc, sf, u_c, u_f)["loss"]
+        assert np.isfinite(first)
+        ctx.close()
