@@ -85,6 +85,9 @@ def main():
                          "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--c-gather", action="store_true",
+                    help="N>1: assemble the frame with the library's own ncclAllGather (nerf_render_image_sharded) "
+                         "instead of torch.distributed.all_gather_into_tensor")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="1-GPU rehearsal of the per-rank work at N=<k>: render only rank 0's slab of a k-way split "
                          "(no collective); the printed value is that slab's rays/s x k (an estimate, not a result)")
@@ -126,7 +129,13 @@ def main():
     if args.rehearse_world > 1 and world == 1:
         begin, count = N.ray_slab(total, 0, args.rehearse_world)
 
+    c_gather = args.c_gather and world > 1 and backend == "nccl"
+    if c_gather:
+        model.ctx.comm_init_from_torch()
+
     def step(seed):
+        if c_gather:
+            return model.ctx.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=seed, device_out=True)
         # whole-slab batch (the library's default); results do not depend on the batch size
         rgb = model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=seed, ray_begin=begin,
                                  ray_count=count, device_out=True, rgb_only=True)[0]

@@ -133,6 +133,20 @@ int nerf_render_image(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int
                       const float* u_coarse, const float* u_fine, uint64_t seed,
                       const nerf_outputs* outs, int mem);
 
+/* ---- multi-GPU assembly from C ------------------------------------------
+ * One process (or thread + ctx) per GPU.  Rank 0 obtains an id and hands it to the others by any means (file, MPI,
+ * a torch store); every rank then joins.  nerf_render_image_sharded renders this rank's contiguous slab of the H*W
+ * rays (equal slabs of ceil(H*W/world) rays, as nerf_and_dietnerf_amd/sharding.py), all-gathers the RGB slabs with ONE
+ * ncclAllGather on the ctx stream and writes the whole (H*W,3) image on every rank.  The Philox counter is the
+ * global ray index: the image does not depend on the number of GPUs.  RCCL is bound at run time (dlopen). */
+#define NERF_COMM_ID_BYTES 128
+int nerf_comm_unique_id(void* id /* NERF_COMM_ID_BYTES, out */);
+int nerf_comm_init(nerf_ctx* ctx, const void* id, int32_t rank, int32_t world);
+int nerf_comm_destroy(nerf_ctx* ctx);
+int nerf_render_image_sharded(nerf_ctx* ctx, const float* c2w, float field_of_view, int32_t H, int32_t W,
+                              int64_t batch, int32_t n_coarse, int32_t n_fine, uint64_t seed,
+                              float* rgb /* (H*W,3) */, int mem);
+
 /* ---- status ------------------------------------------------------------------------------ */
 /* Synchronises and returns (then clears) the number of sample rows whose network output was not finite
  * since the last read.  NERF_PRECISION_F16X3 needs |activations| < 65504 (fp16 range); a non-zero count

@@ -60,6 +60,10 @@ SYMBOLS = [
     ("nerf_render", C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, C.POINTER(NerfOutputs), C.c_int]),
     ("nerf_render_image", C.c_int, [_P, _P, _F, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P, _P, _U64,
                                     C.POINTER(NerfOutputs), C.c_int]),
+    ("nerf_comm_unique_id", C.c_int, [_P]),
+    ("nerf_comm_init", C.c_int, [_P, _P, _I32, _I32]),
+    ("nerf_comm_destroy", C.c_int, [_P]),
+    ("nerf_render_image_sharded", C.c_int, [_P, _P, _F, _I32, _I32, _I64, _I32, _I32, _U64, _P, C.c_int]),
     ("nerf_ctx_read_nonfinite", C.c_int, [_P, C.POINTER(_I64)]),
     ("nerf_train_begin", C.c_int, [_P, C.POINTER(NerfTrainConfig)]),
     ("nerf_train_end", C.c_int, [_P]),

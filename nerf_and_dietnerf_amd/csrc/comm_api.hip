@@ -1,0 +1,143 @@
+// comm_api.hip -- multi-GPU assembly of a frame from C: one process (or thread + ctx) per GPU, rays of independent
+// pixels in contiguous slabs (the partition of nerf_and_dietnerf_amd/sharding.py), ONE ncclAllGather of the RGB slabs over
+// RCCL/xGMI on the ctx stream.  The reference has no distributed layer: this is the C-ABI twin of
+// the torch.distributed path bench.py uses.  RCCL is bound at run time (dlopen) so that single-GPU users of
+// libnerf_mi355.so carry no dependency on it; in a process that already holds a librccl (PyTorch-ROCm bundles one) that
+// copy is reused.
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>   // types and enums only: every entry point is resolved with dlsym
+
+#include "nerf_ctx.h"
+
+using namespace nerf;
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // a copy this process already holds (e.g. torch's)
+    for (const char* n : names)
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail("RCCL is not available (dlopen librccl.so.1: %s)", dlerror());
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+        return fail("librccl lacks an expected entry point");
+    g_rccl = r;
+    return 0;
+}
+
+#define NCCL_OK(expr)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r__));        \
+    } while (0)
+
+}  // namespace
+
+namespace nerf {
+
+struct CommState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf slab, full;
+};
+
+void comm_free(nerf_ctx* c) {
+    if (!c->comm) return;
+    if (c->comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm->comm);
+    if (c->comm->slab.p) (void)hipFree(c->comm->slab.p);
+    if (c->comm->full.p) (void)hipFree(c->comm->full.p);
+    delete c->comm;
+    c->comm = nullptr;
+}
+
+}  // namespace nerf
+
+extern "C" {
+
+int nerf_comm_unique_id(void* id) {
+    if (!id) return fail("id is NULL");
+    if (int r = load_rccl()) return r;
+    static_assert(sizeof(ncclUniqueId) == NERF_COMM_ID_BYTES, "NERF_COMM_ID_BYTES must match ncclUniqueId");
+    NCCL_OK(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id)));
+    return 0;
+}
+
+int nerf_comm_init(nerf_ctx* c, const void* id, int32_t rank, int32_t world) {
+    ENTER(c);
+    if (!id) return fail("id is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad rank %d of %d", rank, world);
+    if (int r = load_rccl()) return r;
+    comm_free(c);
+    CommState* s = new CommState();
+    s->rank = rank; s->world = world;
+    c->comm = s;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t rc = g_rccl.CommInitRank(&s->comm, world, uid, rank);
+    if (rc != ncclSuccess) {
+        s->comm = nullptr;
+        comm_free(c);
+        return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString(rc));
+    }
+    return 0;
+}
+
+int nerf_comm_destroy(nerf_ctx* c) {
+    ENTER(c);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    comm_free(c);
+    return 0;
+}
+
+int nerf_render_image_sharded(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32_t W, int64_t batch, int32_t Sc,
+                              int32_t Sf, uint64_t seed, float* rgb, int mem) {
+    ENTER(c);
+    if (!c->comm || !c->comm->comm) return fail("nerf_comm_init has not been called");
+    if (!c2w || !rgb) return fail("NULL argument");
+    if (H <= 0 || W <= 0) return fail("bad image size %dx%d", H, W);
+    CommState* s = c->comm;
+    const int64_t total = (int64_t)H * W;
+    const int64_t per = (total + s->world - 1) / s->world;             // equal (padded) slabs: a plain all-gather
+    int64_t begin = (int64_t)s->rank * per;
+    if (begin > total) begin = total;
+    const int64_t count = total - begin < per ? total - begin : per;
+    if (int r = ensure(c, s->slab, (size_t)per * 3 * sizeof(float))) return r;
+    if (int r = ensure(c, s->full, (size_t)per * s->world * 3 * sizeof(float))) return r;
+    if (count < per)
+        HIP_OK(hipMemsetAsync((float*)s->slab.p + count * 3, 0, (size_t)(per - count) * 3 * sizeof(float), c->stream));
+    if (count > 0) {
+        nerf_outputs o{};
+        o.rgb = (float*)s->slab.p;
+        if (int r = nerf_render_image(c, c2w, fov, H, W, begin, count, batch, Sc, Sf, nullptr, nullptr, seed, &o,
+                                      NERF_MEM_DEVICE))
+            return r;
+    }
+    NCCL_OK(g_rccl.AllGather(s->slab.p, s->full.p, (size_t)per * 3, ncclFloat, s->comm, c->stream));
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_OK(hipMemcpyAsync(rgb, s->full.p, (size_t)total * 3 * sizeof(float), kind, c->stream));
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -289,6 +289,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         if (n.cst_h) (void)hipFree(n.cst_h);
     }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    comm_free(c);
     train_free(c);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

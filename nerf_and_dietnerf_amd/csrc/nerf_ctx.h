@@ -36,6 +36,7 @@ struct NetWeights {
 };
 
 struct TrainState;   // train_api.hip
+struct CommState;    // comm_api.hip
 
 }  // namespace nerf
 
@@ -55,6 +56,7 @@ struct nerf_ctx {
     long long timed_rows = 0;
     unsigned long long* nonfinite = nullptr;   // device counter fed by the MLP kernels
     nerf::TrainState* train = nullptr;         // optimizer state + training buffers (nerf_train_begin)
+    nerf::CommState* comm = nullptr;           // RCCL communicator + slab buffers (nerf_comm_init)
 };
 
 namespace nerf {
@@ -65,6 +67,7 @@ int enter(nerf_ctx* c);                             // NULL check + hipSetDevice
 #define ENTER(c) do { if (int r__ = nerf::enter(c)) return r__; } while (0)
 
 void train_free(nerf_ctx* c);                       // train_api.hip: releases c->train (called by nerf_ctx_destroy)
+void comm_free(nerf_ctx* c);                        // comm_api.hip: releases c->comm (called by nerf_ctx_destroy)
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob_host);   // nerf_api.hip: pack + upload streams
 int train_on_load(nerf_ctx* c, int which);          // train_api.hip: no-op without a trainer
 int train_flush_weights(nerf_ctx* c, int which);

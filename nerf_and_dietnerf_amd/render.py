@@ -158,6 +158,44 @@ class Context:
         _lib.check(self.lib.nerf_ctx_read_nonfinite(self.h, C.byref(n)))
         return n.value
 
+    # ---- multi-GPU assembly through the C ABI (RCCL all-gather inside the library) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """An RCCL unique id (rank 0 creates it and hands it to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().nerf_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.lib.nerf_comm_init(self.h, buf, rank, world))
+
+    def comm_init_from_torch(self, group=None) -> None:
+        """Join the ranks of an initialised torch.distributed group (the id travels through its store)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.comm_init(box[0], rank, world)
+
+    def comm_destroy(self) -> None:
+        _lib.check(self.lib.nerf_comm_destroy(self.h))
+
+    def render_image_sharded(self, c2w, fov, h, w, batch, n_c, n_f, seed=0, device_out=False):
+        """This rank renders its slab, ONE ncclAllGather inside the library assembles (h,w,3) on every rank."""
+        c2w_h = np.ascontiguousarray(np.asarray(c2w, np.float32))
+        if device_out:
+            import torch
+            out = torch.empty((h, w, 3), dtype=torch.float32, device=torch.device("cuda", self.cfg.device))
+            self._arrays(out)                    # device result => enqueue on torch's current stream
+            ptr, mem = out.data_ptr(), NERF_MEM_DEVICE
+        else:
+            out = np.empty((h, w, 3), np.float32)
+            ptr, mem = out.ctypes.data, NERF_MEM_HOST
+        _lib.check(self.lib.nerf_render_image_sharded(self.h, c2w_h.ctypes.data, float(fov), h, w, batch, n_c, n_f, seed,
+                                                      ptr, mem))
+        return out
+
     # ---- training (NeRF.train_step, src/NeRF.py:136-178) ----
     def train_begin(self, learning_rate: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
                     sampler_gradient: bool = True) -> None:

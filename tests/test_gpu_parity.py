@@ -651,3 +651,24 @@ def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):
         assert ctx.read_nonfinite() == 0
     finally:
         ctx.set_precision("fp32")
+
+
+def test_c_level_rccl_assembly_world_1(nerf, golden_vec):
+    """nerf_comm_* + nerf_render_image_sharded (the RCCL all-gather inside the C library, bound by dlopen) with a
+    one-rank communicator: the assembled frame is bit-identical to nerf_render_image.  (More ranks need more GPUs than
+    this box has; the slab arithmetic is the one tests/test_dist_gloo.py and the slab-invariance test pin.)"""
+    import nerf_and_dietnerf_amd as N
+    ctx = nerf.ctx
+    ctx.comm_init(N.Context.comm_unique_id(), 0, 1)
+    try:
+        fov, c2w = float(golden_vec["fov"]), golden_vec["c2w"]
+        for (h, w) in ((50, 50), (7, 13)):
+            full = ctx.render_image_sharded(c2w, fov, h, w, 4096, 64, 128, seed=11)
+            ref = ctx.render_image(c2w, fov, h, w, 4096, 64, 128, seed=11)[0]
+            np.testing.assert_array_equal(full, ref)
+        dev = ctx.render_image_sharded(c2w, fov, 50, 50, 4096, 64, 128, seed=11, device_out=True)
+        np.testing.assert_array_equal(dev.cpu().numpy(), ctx.render_image(c2w, fov, 50, 50, 4096, 64, 128, seed=11)[0])
+    finally:
+        ctx.comm_destroy()
+    with pytest.raises(RuntimeError, match="nerf_comm_init"):
+        ctx.render_image_sharded(golden_vec["c2w"], 0.5, 4, 4, 4096, 8, 8)
