@@ -175,7 +175,10 @@ int nerf_train_end(nerf_ctx* ctx);
 int nerf_train_set_learning_rate(nerf_ctx* ctx, float learning_rate);
 /* One NeRF.train_step on N rays: rays_orig/rays_dirs (N,4), target_rgb (N,3); u_coarse (N,Sc) / u_fine (N,Sf)
  * NULL -> on-device Philox(seed, ray index in the batch).  metrics (host, nullable): loss, psnr_coarse, psnr_fine;
- * passing it synchronises.  Sf = 0 (or no fine network) trains the coarse network alone (src/NeRF.py:153). */
+ * passing it synchronises.  Sf = 0 (or no fine network) trains the coarse network alone (src/NeRF.py:153).
+ * With a communicator (nerf_comm_init, world > 1) the step is data-parallel: every rank passes its own shard of the
+ * batch and the two gradient blobs are averaged with one ncclAllReduce each before the (identical) Adam update;
+ * metrics are this rank's. */
 int nerf_train_step(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* target_rgb,
                     int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
                     float* metrics, int mem);

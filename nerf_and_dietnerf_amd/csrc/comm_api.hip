@@ -20,6 +20,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -39,8 +40,9 @@ int load_rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail("librccl lacks an expected entry point");
     g_rccl = r;
     return 0;
@@ -61,6 +63,21 @@ struct CommState {
     int rank = 0, world = 1;
     DevBuf slab, full;
 };
+
+__global__ void scale_kernel(float* __restrict__ x, size_t n, float s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+// mean over the ranks of the ctx's communicator, in place on the ctx stream; no-op without a communicator
+int comm_allreduce_mean(nerf_ctx* c, float* buf, size_t n) {
+    if (!c->comm || !c->comm->comm || c->comm->world == 1) return 0;
+    NCCL_OK(g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm->comm, c->stream));
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, buf, n,
+                       1.0f / (float)c->comm->world);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
 
 void comm_free(nerf_ctx* c) {
     if (!c->comm) return;

@@ -560,6 +560,11 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
     const bool fine = Sf > 0 && c->train->net[1].present;
     if (!fine && c->train->net[1].present)   // a skipped fine pass must not move the fine network
         HIP_OK(hipMemsetAsync(c->train->net[1].grad, 0, c->train->nblob * sizeof(float), c->stream));
+    // data-parallel: with a communicator (nerf_comm_init) every rank passes its shard of the batch and the gradient
+    // blobs are averaged here, one all-reduce each, before the identical Adam update
+    for (int w = 0; w < 2; ++w)
+        if (c->train->net[w].present)
+            if (int r = comm_allreduce_mean(c, c->train->net[w].grad, c->train->nblob)) return r;
     if (int r = apply_impl(c)) return r;
     return read_metrics(c, fine, metrics);
 }

@@ -422,3 +422,23 @@ def test_train_edge_shapes_and_transparent_scene(oracle, golden_ckpt, n, sc, sf)
         first = ctx.train_step(o, d, tgt, sc, sf, u_c, u_f)["loss"]
         assert np.isfinite(first)
         ctx.close()
+
+
+def test_train_step_with_one_rank_communicator(oracle, golden_ckpt):
+    """nerf_train_step under a (one-rank) RCCL communicator == without one: the in-library gradient all-reduce is a
+    no-op at world 1 and must not disturb the step."""
+    import nerf_and_dietnerf_amd as N
+    p = _problem(oracle, golden_ckpt, n=32, sc=8, sf=8, seed=13)
+    res = []
+    for with_comm in (False, True):
+        ctx = _ctx(p)
+        if with_comm:
+            ctx.comm_init(N.Context.comm_unique_id(), 0, 1)
+        ctx.train_begin(5e-4)
+        for _ in range(2):
+            m = ctx.train_step(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+        res.append((m["loss"], ctx.get_weights(0), ctx.get_weights(1)))
+        ctx.close()
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
