@@ -38,6 +38,45 @@ int main(int argc, char** argv) {
     printf("checksum %.9f\n", sum);
     printf("pixel0 %.9g %.9g %.9g depth0 %.9g\n", rgb[0], rgb[1], rgb[2], depth[0]);
     printf("pixel255 %.9g %.9g %.9g depth255 %.9g\n", rgb[255 * 3], rgb[255 * 3 + 1], rgb[255 * 3 + 2], depth[255]);
+    /* the same frame through the library's own RCCL assembly with a one-rank communicator (no torch in this process:
+     * librccl is found by dlopen) */
+    {
+        char id[NERF_COMM_ID_BYTES];
+        float* full = (float*)malloc(sizeof(float) * H * W * 3);
+        if (nerf_comm_unique_id(id) || nerf_comm_init(ctx, id, 0, 1) ||
+            nerf_render_image_sharded(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 64, 128, 12345u, full, NERF_MEM_HOST)) {
+            fprintf(stderr, "comm: %s\n", nerf_last_error()); return 1;
+        }
+        int same = 1;
+        for (int i = 0; i < H * W * 3; ++i) same &= full[i] == rgb[i];
+        printf("sharded_equal %d\n", same);
+        nerf_comm_destroy(ctx);
+        free(full);
+    }
+    /* three training steps (NeRF.train_step) on the rays of that frame towards a constant colour: the loss must fall */
+    {
+        const int N = H * W;
+        float* dirs = (float*)malloc(sizeof(float) * N * 4);
+        float* orig = (float*)malloc(sizeof(float) * N * 4);
+        float* tgt = (float*)malloc(sizeof(float) * N * 3);
+        if (nerf_get_rays_directions(ctx, buf + 2 * nb, 0.6911112f, H, W, dirs, NERF_MEM_HOST)) {
+            fprintf(stderr, "dirs: %s\n", nerf_last_error()); return 1;
+        }
+        for (int i = 0; i < N; ++i) {
+            for (int k = 0; k < 4; ++k) orig[i * 4 + k] = buf[2 * nb + k * 4 + 3];      /* c2w[:, 3] */
+            tgt[i * 3] = 0.8f; tgt[i * 3 + 1] = 0.3f; tgt[i * 3 + 2] = 0.1f;
+        }
+        nerf_train_config tc = {5e-4f, 0.9f, 0.999f, 1e-7f, 1};
+        float m0[3], m1[3];
+        if (nerf_train_begin(ctx, &tc) ||
+            nerf_train_step(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 1u, m0, NERF_MEM_HOST) ||
+            nerf_train_step(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 1u, m1, NERF_MEM_HOST) ||
+            nerf_train_step(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 1u, m1, NERF_MEM_HOST) || nerf_train_end(ctx)) {
+            fprintf(stderr, "train: %s\n", nerf_last_error()); return 1;
+        }
+        printf("train_loss %.9g %.9g\n", m0[0], m1[0]);
+        free(dirs); free(orig); free(tgt);
+    }
     nerf_ctx_destroy(ctx);
     free(buf); free(rgb); free(depth);
     return 0;

@@ -563,6 +563,10 @@ def test_c_abi_client(tmp_path, oracle):
     np.testing.assert_array_equal(got[:3], out[0].reshape(-1, 3)[255])
     np.testing.assert_array_equal(got[3], out[6].reshape(-1)[255])
     ctx.close()
+    # the plain-C process also went through the in-library RCCL assembly and three training steps
+    assert re.search(r"sharded_equal 1", res.stdout), res.stdout
+    tl = re.search(r"train_loss (\S+) (\S+)", res.stdout)
+    assert tl and 0 < float(tl.group(2)) < float(tl.group(1)), res.stdout
 
 
 def test_nonfinite_watch(golden_ckpt, golden_vec):
