@@ -96,9 +96,11 @@ __device__ __forceinline__ void split_trunc(float y, float& hi_f, float& lo_f) {
 //   back as the last tile's chain retires the k-steps that read them; tile 7 lands in xh/xl[14..15].
 // FAST = single-pass fp16 mode (NERF_PRECISION_F16: the reference's production mixed_float16 numerics): only the
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
-template <int BODY, bool PENDING, bool FAST>
+// STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
+// of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store.
+template <int BODY, bool PENDING, bool FAST, bool STASH = false>
 __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
-                                             float alpha, f32x16 (&accs)[4],
+                                             float alpha, float* st_prev, float* st_cur, f32x16 (&accs)[4],
                                              frag4 (&xh)[16], frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14],
                                              const frag4 (&peh)[3], const frag4 (&pel)[3], const frag4 (&dh)[2],
                                              const frag4 (&dl)[2], float (&xc)[64], float& sigma_raw) {
@@ -152,10 +154,24 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             dst[4 * g + 0] = b[0]; dst[4 * g + 1] = b[1]; dst[4 * g + 2] = b[2]; dst[4 * g + 3] = b[3];
         });
     };
-    auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel) {
+    float sq0 = 0.f, sq1 = 0.f;      // first half of the float4 being collected for the stash
+    (void)sq0; (void)sq1;
+    auto stash4 = [&](auto utc, auto rc, float y0, float y1, float* base) {
+        // registers r..r+1 of output tile ut = features 32 ut + 8 (r >> 2) + 4 h + (r & 3) .. (+1); h sits in `base`
+        constexpr int ut = decltype(utc)::value;
+        constexpr int r = decltype(rc)::value;
+        if constexpr ((r & 3) == 0) { sq0 = y0; sq1 = y1; }
+        else {
+            f32x4 v;
+            v[0] = sq0; v[1] = sq1; v[2] = y0; v[3] = y1;
+            *reinterpret_cast<f32x4*>(base + 32 * ut + 8 * (r >> 2)) = v;
+        }
+    };
+    auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel, auto pend_sel) {
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         constexpr int n = 2 * ut + (r >> 3), e = r & 7;
+        if constexpr (STASH) stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
         if constexpr (FAST) {
             const uint32_t ph = pack_h2(y0, y1);                          // round to fp16, no lo part
             if constexpr (decltype(dest_sel)::value) xh[n][e >> 1] = ph;
@@ -240,12 +256,18 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             if constexpr (kPend) {
                 constexpr int er = 2 * n;
                 const float y0 = act(prv[er]), y1 = act(prv[er + 1]);
-                store_pair(std::integral_constant<int, 7>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{});
+                store_pair(std::integral_constant<int, 7>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{}, std::true_type{});
             } else if constexpr (kPrevS) {
                 const float y = act(prv[n]);
-                if constexpr (kXc) xc[et * 16 + n] = y;
+                if constexpr (kXc) {
+                    xc[et * 16 + n] = y;
+                    if constexpr (STASH) {      // layer 8's outputs (128 features) go to the stash in fours as well
+                        if constexpr ((n & 1) == 0) ycarry = y;
+                        else stash4(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, st_cur);
+                    }
+                }
                 else if constexpr ((n & 1) == 0) ycarry = y;
-                else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, std::false_type{});
+                else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, std::false_type{}, std::false_type{});
             }
             if constexpr (u == 0 && PENDING) {
                 // previous layer's tile 6 sits complete in nh/nl[12..13]; its k-steps are long retired
@@ -263,8 +285,8 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 static_for<0, 8>([&](auto pc) {
                     constexpr int r = 2 * decltype(pc)::value;
                     const float z0 = act(prv[r]), z1 = act(prv[r + 1]);
-                    if constexpr (u - 1 <= 5) store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::true_type{});
-                    else store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::false_type{});
+                    if constexpr (u - 1 <= 5) store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::true_type{}, std::false_type{});
+                    else store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::false_type{}, std::false_type{});
                 });
             }
             // last tile of an in-place layer: fragment m-1 of x-in died with k-step m-1; tiles 0..5 of
@@ -301,7 +323,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo
     }
 }
 
-template <bool FAST>
+template <bool FAST, bool STASH = false>
 __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -401,20 +423,31 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             split8<FAST>(t8, dh[n], dl[n]);
         }
 
+        // stash rows of this lane's sample (rows beyond M exist: the buffers are padded to whole 128-row tiles)
+        auto st_of = [&](int l) -> float* {
+            if constexpr (!STASH) return nullptr;
+            else return a.st_ptr[l] + (tile * 128 + wave * 32 + j) * (long long)a.st_ld[l] + 4 * h;
+        };
+        float* st_prev = nullptr;
+        float* st_cur = st_of(0);
         STAMP(t1); acc_t[0] += t1 - t0;
-        layer_body_h<BODY_PE, false, FAST>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        layer_body_h<BODY_PE, false, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
+            st_prev = st_cur;
+            st_cur = st_of(l);
             if (l == 4) {
-                layer_body_h<BODY_SKIP, true, FAST>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_SKIP, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
             } else {
-                layer_body_h<BODY_HID, true, FAST>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_HID, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
-        layer_body_h<BODY_LAST, true, FAST>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        st_prev = st_cur;
+        st_cur = st_of(8);
+        layer_body_h<BODY_LAST, true, FAST, STASH>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t1); acc_t[4] += t1 - t0;
 
         // rgb head (128 -> 3) on the VALU in fp32
@@ -458,6 +491,14 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
 
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) { mlp_f16_body<false>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16_kernel(const MlpArgs a) { mlp_f16_body<true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16x3_stash_kernel(const MlpArgs a) { mlp_f16_body<false, true>(a); }
+
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream) {
+    if (a.M <= 0) return;
+    const long long ntiles = (a.M + 127) / 128;
+    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    hipLaunchKernelGGL(mlp_f16x3_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+}
 
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass) {
     if (a.M <= 0) return;
@@ -478,6 +519,8 @@ void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_stash_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
@@ -534,26 +577,26 @@ int h_dir_row(int v, int h, int n_angles) {   // slot v (0..15) -> row of the di
 struct HLayer { const float* k; const float* b; int in, out; };
 }  // namespace
 
-static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_out, float* const_out, bool hi_only) {
+// The packing as a pure index map: EmitW(pos_hi, pos_lo (-1 in the hi-only stream), src) for every 16-bit slot pair of
+// the stream, EmitC(pos, src) for every float of the constant region; src = index into the blob, -1 = zero padding.
+template <class EmitW, class EmitC>
+static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c) {
     const int kd = 256 + 8 * (n_angles + 1);
     const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
                                {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
-    HLayer L[11];
-    size_t off = 0;
+    struct Lay { long long k, b; int in, out; } L[11];
+    long long off = 0;
     for (int i = 0; i < 11; ++i) {
         L[i].in = shapes[i][0]; L[i].out = shapes[i][1];
-        L[i].k = blob + off; off += (size_t)L[i].in * L[i].out;
-        L[i].b = blob + off; off += L[i].out;
+        L[i].k = off; off += (long long)L[i].in * L[i].out;
+        L[i].b = off; off += L[i].out;
     }
-    memset(stream_out, 0, hi_only ? kStreamBytesF16Hi : kStreamBytesF16);
-    memset(const_out, 0, kConstBytes);
-    uint16_t* base = reinterpret_cast<uint16_t*>(stream_out);
     size_t chunk = 0;
     auto emit_body = [&](int layer, int body) {
         const int NU = body == BODY_LAST ? kHTilesLast : 8;
         const int NSTEP = body == BODY_PE ? kHStepsPE : body == BODY_HID ? kHStepsHid
                           : body == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
-        uint16_t* b0 = base + chunk * (kHChunkBytes / 2);
+        const long long b0 = (long long)chunk * (kHChunkBytes / 2);
         for (int u = 0; u < NU; ++u)
             for (int n = 0; n < NSTEP; ++n)
                 for (int lane = 0; lane < 64; ++lane)
@@ -569,19 +612,16 @@ static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_
                             if (n < kHStepsHid) row = h_hid_row(n, e, h);
                             else { const int r = h_dir_row((n - kHStepsHid) * 8 + e, h, n_angles); row = r < 0 ? -1 : kHidden + r; }
                         }
-                        float w = 0.f;
+                        long long src = -1;
                         if (row >= 0) {
-                            if (body == BODY_LAST && u == kHTilesLast - 1) w = i == 0 ? L[10].k[row] : 0.f;   // sigma row
-                            else w = L[layer].k[(size_t)row * L[layer].out + 32 * u + i];
+                            if (body == BODY_LAST && u == kHTilesLast - 1) src = i == 0 ? L[10].k + row : -1;   // sigma row
+                            else src = L[layer].k + (long long)row * L[layer].out + 32 * u + i;
                         }
-                        const uint16_t hi = f32_to_f16(w);
-                        const uint16_t lo = f32_to_f16(w - f16_to_f32(hi));
                         if (hi_only) {
-                            b0[(size_t)(u * NSTEP + n) * (kQuadBytes / 2) + lane * 8 + e] = hi;
+                            emit_w(b0 + (long long)(u * NSTEP + n) * (kQuadBytes / 2) + lane * 8 + e, -1LL, src);
                         } else {
-                            const size_t q = (size_t)(u * NSTEP + n) * 2;
-                            b0[(q + 0) * (kQuadBytes / 2) + lane * 8 + e] = hi;
-                            b0[(q + 1) * (kQuadBytes / 2) + lane * 8 + e] = lo;
+                            const long long q = (long long)(u * NSTEP + n) * 2;
+                            emit_w(b0 + (q + 0) * (kQuadBytes / 2) + lane * 8 + e, b0 + (q + 1) * (kQuadBytes / 2) + lane * 8 + e, src);
                         }
                     }
         chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kHCQ - 1) / kHCQ;
@@ -592,12 +632,68 @@ static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_
     for (int l = 5; l <= 7; ++l) emit_body(l, BODY_HID);
     emit_body(8, BODY_LAST);
     for (int l = 0; l < 8; ++l)
-        for (int f = 0; f < 256; ++f) const_out[kHConstBias + l * 256 + f] = L[l].b[f];
-    for (int f = 0; f < 128; ++f) const_out[kHConstBias8 + f] = L[8].b[f];
-    const_out[kHConstBiasSig + 0] = L[10].b[0];
+        for (int f = 0; f < 256; ++f) emit_c(kHConstBias + l * 256 + f, L[l].b + f);
+    for (int f = 0; f < 128; ++f) emit_c(kHConstBias8 + f, L[8].b + f);
+    emit_c(kHConstBiasSig + 0, L[10].b);
     for (int c = 0; c < 3; ++c)
-        for (int f = 0; f < 128; ++f) const_out[kHConstWrgb + c * 128 + f] = L[9].k[f * 3 + c];
-    for (int c = 0; c < 3; ++c) const_out[kHConstBHead + c] = L[9].b[c];
+        for (int f = 0; f < 128; ++f) emit_c(kHConstWrgb + c * 128 + f, L[9].k + f * 3 + c);
+    for (int c = 0; c < 3; ++c) emit_c(kHConstBHead + c, L[9].b + c);
+}
+
+static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_out, float* const_out, bool hi_only) {
+    memset(stream_out, 0, hi_only ? kStreamBytesF16Hi : kStreamBytesF16);
+    memset(const_out, 0, kConstBytes);
+    uint16_t* base = reinterpret_cast<uint16_t*>(stream_out);
+    pack_f16_map(n_angles, hi_only,
+                 [&](long long ph, long long pl, long long src) {
+                     const float w = src < 0 ? 0.f : blob[src];
+                     const uint16_t hi = f32_to_f16(w);
+                     base[ph] = hi;
+                     if (pl >= 0) base[pl] = f32_to_f16(w - f16_to_f32(hi));
+                 },
+                 [&](long long pos, long long src) { const_out[pos] = blob[src]; });
+}
+
+// gather tables of the 3-pass stream for the device-side re-pack (the trainer's forward runs on this kernel and its
+// weights change every step): stream_idx[slot] = 2 * (src + 1) + is_lo, const_idx[float] = src + 1; 0 = padding
+void build_f16x3_gather(int n_angles, int32_t* stream_idx /*kStreamBytesF16 / 2*/, int32_t* const_idx /*kConstFloats*/) {
+    memset(stream_idx, 0, (kStreamBytesF16 / 2) * sizeof(int32_t));
+    memset(const_idx, 0, kConstFloats * sizeof(int32_t));
+    pack_f16_map(n_angles, false,
+                 [&](long long ph, long long pl, long long src) {
+                     if (src < 0) return;
+                     stream_idx[ph] = (int32_t)(2 * (src + 1));
+                     stream_idx[pl] = (int32_t)(2 * (src + 1) + 1);
+                 },
+                 [&](long long pos, long long src) { const_idx[pos] = (int32_t)(src + 1); });
+}
+
+__global__ void repack_f16x3_kernel(const float* __restrict__ blob, const int32_t* __restrict__ stream_idx,
+                                    uint16_t* __restrict__ stream, const int32_t* __restrict__ const_idx,
+                                    float* __restrict__ cst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kStreamBytesF16 / 2) {
+        const int32_t t = stream_idx[i];
+        uint16_t out = 0;
+        if (t != 0) {
+            const float w = blob[(t >> 1) - 1];
+            const _Float16 hi = (_Float16)w;                       // RNE, as the host packer
+            const _Float16 v = (t & 1) ? (_Float16)(w - (float)hi) : hi;
+            out = __builtin_bit_cast(uint16_t, v);
+        }
+        stream[i] = out;
+    }
+    if (i < (size_t)kConstFloats) {
+        const int32_t t = const_idx[i];
+        cst[i] = t ? blob[t - 1] : 0.f;
+    }
+}
+
+void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
+                         hipStream_t s) {
+    const size_t n = kStreamBytesF16 / 2;
+    hipLaunchKernelGGL(repack_f16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blob, stream_idx,
+                       reinterpret_cast<uint16_t*>(stream), const_idx, cst);
 }
 
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out) {

@@ -122,7 +122,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         return layerwise_forward(c, which, in_a, in_b, z, raw, M, S, mode);
     }
     const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3 || c->cfg.precision == NERF_PRECISION_F16;
-    MlpArgs a;
+    MlpArgs a{};
     a.wstream = c->cfg.precision == NERF_PRECISION_F16 ? (const float*)c->net[which].stream_h1
                 : f16 ? (const float*)c->net[which].stream_h : c->net[which].stream;
     a.wconst = f16 ? c->net[which].cst_h : c->net[which].cst;

@@ -66,6 +66,10 @@ struct MlpArgs {
     int S;                  // samples per ray (mode 0)
     int mode;
     float alpha;            // LeakyReLU slope
+    // training forward (mlp_f16x3 "stash" kernel only): where the fp32 activation of layer l = 0..8 is written,
+    // row-major with leading dimension st_ld[l] (rows padded to a multiple of 128); unused (null) when rendering
+    float* st_ptr[9];
+    int st_ld[9];
 };
 
 // mlp_fp32.hip
@@ -76,6 +80,11 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStr
 
 // mlp_f16x3.hip
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);   // single_pass: hi*hi only
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream);   // 3-pass forward that also writes a.st_ptr
+// device-side re-pack of the 3-pass stream + constants from a blob (tables from build_f16x3_gather, host)
+void build_f16x3_gather(int n_angles, int32_t* stream_idx /*kStreamBytesF16/2*/, int32_t* const_idx /*kConstFloats*/);
+void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
+                         hipStream_t s);
 void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 void pack_weights_f16(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16Hi*/, float* const_out /*kConstFloats*/);

@@ -5,7 +5,10 @@
 // context's stream.  Master weights, gradients and Adam moments live on the device as flat blobs in Keras
 // get_weights() order; padded [K x N] / [N x K] copies feed the GEMMs and are rebuilt after every update.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <vector>
 
 #include "nerf_ctx.h"
 #include "train_kernels.h"
@@ -24,6 +27,8 @@ struct TNet {
     bool present = false;
     bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
+    void* fstream = nullptr;       // fused forward (f16x3 stash kernel): operand stream + constants, re-packed on device
+    float* fcst = nullptr;
     int n_layers = 11;             // 11: xyz + view-direction network; 12: xyz-only network (n_angles_for_model = 0)
     TLayer L[12];
 };
@@ -35,6 +40,8 @@ struct TPass {                      // activations of one pass, kept from forwar
 struct TrainState {
     nerf_train_config cfg;
     bool training = false;          // false: created only to serve the layer-wise forward of the xyz-only network
+    bool fused_forward = false;     // forward pass on the fused split-fp16 kernel with activation stash (n_angles > 0)
+    int32_t *sidx = nullptr, *cidx = nullptr;   // device gather tables of the fused kernel's stream / constants
     long long step = 0;
     size_t nblob = 0;
     TNet net[2];
@@ -74,6 +81,7 @@ int layer_table(const nerf_config& cfg, TLayer L[12]) {
 void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 int relayout_net(nerf_ctx* c, TNet& n) {
+    if (n.fstream) launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->stream);
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
@@ -97,6 +105,22 @@ int alloc_optimizer(nerf_ctx* c, TrainState* t, TNet& n) {
     return 0;
 }
 
+// fused-forward operands of one network (and, once, the gather tables they are re-packed with)
+int ensure_fused(nerf_ctx* c, TrainState* t, TNet& n) {
+    if (!t->fused_forward) return 0;
+    if (!t->sidx) {
+        std::vector<int32_t> si(kStreamBytesF16 / 2), ci(kConstFloats);
+        build_f16x3_gather(c->cfg.n_angles, si.data(), ci.data());
+        HIP_OK(hipMalloc((void**)&t->sidx, si.size() * sizeof(int32_t)));
+        HIP_OK(hipMalloc((void**)&t->cidx, ci.size() * sizeof(int32_t)));
+        HIP_OK(hipMemcpy(t->sidx, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(t->cidx, ci.data(), ci.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (!n.fstream) HIP_OK(hipMalloc(&n.fstream, kStreamBytesF16));
+    if (!n.fcst) HIP_OK(hipMalloc((void**)&n.fcst, kConstBytes));
+    return 0;
+}
+
 int init_net(nerf_ctx* c, TrainState* t, int which) {
     TNet& n = t->net[which];
     n.n_layers = layer_table(c->cfg, n.L);
@@ -117,6 +141,7 @@ int init_net(nerf_ctx* c, TrainState* t, int which) {
     HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), nb, hipMemcpyHostToDevice, c->stream));
     n.present = true;
     n.render_dirty = false;
+    if (int r = ensure_fused(c, t, n)) return r;
     return relayout_net(c, n);
 }
 
@@ -180,7 +205,21 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
     TPass& p = t->pass[which];
     float *raw = (float*)p.raw.p, *z = (float*)p.z.p;
     launch_train_encode(o, dirs, z, 0, d.M, d.S, d.Mp, c->cfg.n_angles, 0, (float*)p.C4.p, (float*)p.C8.p, c->stream);
-    forward_layers(c, n, p, d.Mp, raw);
+    if (t->fused_forward && n.fstream) {
+        // the render path's fused PE + MLP kernel (3-pass split fp16, fp32-class results) with every activation also
+        // written to the buffers the backward GEMMs read: 4x the rate of the layer-wise forward
+        MlpArgs a{};
+        a.wstream = (const float*)n.fstream; a.wconst = n.fcst;
+        a.in_a = o; a.in_b = dirs; a.z = z; a.raw = raw; a.nonfinite = c->nonfinite;
+        a.M = d.M; a.S = d.S; a.mode = 0; a.alpha = c->cfg.leaky_relu_alpha;
+        float* dst[9] = {(float*)p.H1.p, (float*)p.H2.p, (float*)p.H3.p, (float*)p.C4.p, (float*)p.H5.p,
+                         (float*)p.H6.p, (float*)p.H7.p, (float*)p.C8.p, (float*)p.H9.p};
+        const int ld[9] = {256, 256, 256, kLdC4, 256, 256, 256, kLdC8, 128};
+        for (int i = 0; i < 9; ++i) { a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i]; }
+        launch_mlp_f16x3_stash(a, c->num_cus, c->stream);
+    } else {
+        forward_layers(c, n, p, d.Mp, raw);
+    }
     launch_composite(raw, z, d.N, d.S, (float*)p.rgb.p, (float*)p.w.p, (float*)p.T.p, nullptr, nullptr, nullptr,
                      c->stream);
     HIP_OK(hipGetLastError());
@@ -393,7 +432,11 @@ void train_free(nerf_ctx* c) {
         if (n.m) (void)hipFree(n.m);
         if (n.v) (void)hipFree(n.v);
         if (n.mats) (void)hipFree(n.mats);
+        if (n.fstream) (void)hipFree(n.fstream);
+        if (n.fcst) (void)hipFree(n.fcst);
     }
+    if (t->sidx) (void)hipFree(t->sidx);
+    if (t->cidx) (void)hipFree(t->cidx);
     TPass* passes[] = {&t->pass[0], &t->pass[1], &t->infer};
     for (TPass* pp : passes) {
         TPass& p = *pp;
@@ -487,11 +530,19 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     t->cfg = *cfg;
     t->training = true;
     t->step = 0;
+    // forward on the fused kernel unless the network has no fused kernel (xyz-only) or NERF_TRAIN_FORWARD=gemm asks
+    // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
+    const char* fw = getenv("NERF_TRAIN_FORWARD");
+    t->fused_forward = c->cfg.n_angles != 0 && !(fw && strcmp(fw, "gemm") == 0);
     for (int w = 0; w < 2; ++w) {
         if (!c->net[w].loaded) continue;
         if (!t->net[w].present) {
             if (int r = init_net(c, t, w)) { train_free(c); return r; }
-        } else if (int r = alloc_optimizer(c, t, t->net[w])) { train_free(c); return r; }
+        } else {
+            if (int r = alloc_optimizer(c, t, t->net[w])) { train_free(c); return r; }
+            if (int r = ensure_fused(c, t, t->net[w])) { train_free(c); return r; }
+            if (int r = relayout_net(c, t->net[w])) { train_free(c); return r; }
+        }
     }
     return 0;
 }
