@@ -46,7 +46,8 @@ struct TrainState {
     size_t nblob = 0;
     TNet net[2];
     TPass pass[2];
-    DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal;
+    DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal, gmax;
+    bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
@@ -228,15 +229,20 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
 
 // ---- one pass: backward --------------------------------------------------------------------------
 void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
-           int n_src_off, long long Mp) {
+           int n_src_off, long long Mp, const unsigned* gmax = nullptr) {
     const TLayer& L = n.L[l];
     GemmAtb g{};
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
     g.partial = (float*)t->partial.p; g.Kp = L.Kp; g.Nw = Ncols; g.M = Mp;
-    long long rps = (Mp + kTrainSplits - 1) / kTrainSplits;
+    // the heads' (K x 4) results come from a VALU kernel that wants many small slabs; the GEMMs use kTrainSplits
+    const int want_splits = Ncols == 4 ? 256 : kTrainSplits;
+    long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 15) / 16 * 16;
     g.rows_per_split = (int)rps;
-    launch_gemm_atb(g, c->stream);
+    g.gmax = gmax;
+    if (Ncols == 4) launch_head_wgrad(g, c->stream);
+    else if (t->wgrad_f16 && gmax && Ncols >= 128) launch_gemm_atb_h(g, c->stream);
+    else launch_gemm_atb(g, c->stream);
     ReduceArgs r{};
     r.partial = g.partial; r.Kp = L.Kp; r.Nw = Ncols; r.splits = (int)((Mp + rps - 1) / rps);
     r.grad_w = n.grad + L.w_off; r.grad_b = n.grad + L.b_off;
@@ -245,8 +251,9 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
 }
 
 void dgrad(nerf_ctx* c, const float* G, int ldg, int Kg, const float* Wrows, int ldb, int Nout, const float* H, int ldh,
-           float* Out, int ldo, long long Mp, const float* r1a = nullptr, const float* r1b = nullptr) {
+           float* Out, int ldo, long long Mp, unsigned* gmax_out, const float* r1a = nullptr, const float* r1b = nullptr) {
     GemmAbt g{};
+    g.gmax = gmax_out;
     g.A = G; g.lda = ldg; g.Bt = Wrows; g.ldb = ldb; g.Out = Out; g.ldo = ldo;
     g.M = Mp; g.N = Nout; g.K = Kg; g.H = H; g.ldh = ldh; g.r1a = r1a; g.r1a_ld = 4; g.r1b = r1b;
     g.n_valid = Nout; g.alpha = c->cfg.leaky_relu_alpha;
@@ -273,40 +280,44 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     float *Ga = (float*)t->Ga.p, *Gb = (float*)t->Gb.p, *G9 = (float*)t->G9.p, *Graw = (float*)t->Graw.p,
           *dA0 = (float*)t->dA0.p;
     const bool dx = d_z != nullptr;
+    // gm[k]: bits of max|G| of the gradient buffer produced k-th in this pass (scale of the split-fp16 weight gradient)
+    unsigned* gm = t->wgrad_f16 ? (unsigned*)t->gmax.p : nullptr;      // exact-fp32 weight gradients need no scale
+    if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
+    auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
     if (n.n_layers == 11) {
         wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-        launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
-        wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp);
+        launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, GM(0), c->stream);
+        wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp, GM(0));
         // dL/dh8 = G9 . W8[hidden rows]^T + Graw[:,3] * W10[hidden rows]   (WT10 row 0 = the sigma head's column)
-        dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[10].WT);
+        dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[10].WT);
     } else {
         float* H8b = (float*)p.H8b.p;
         wgrad(c, t, n, 10, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 11, C8, kLdC8, Graw, 4, 4, 3, Mp);
-        launch_head_bwd(Graw, n.L[10].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, c->stream);
-        wgrad(c, t, n, 9, H8b, 256, G9, 128, 128, 0, Mp);
-        dgrad(c, G9, 128, 128, n.L[9].W, 128, 256, H8b, 256, Gb, 256, Mp);            // -> pre-activation grad of h8b
-        wgrad(c, t, n, 8, C8, kLdC8, Gb, 256, 256, 0, Mp);
+        launch_head_bwd(Graw, n.L[10].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, GM(0), c->stream);
+        wgrad(c, t, n, 9, H8b, 256, G9, 128, 128, 0, Mp, GM(0));
+        dgrad(c, G9, 128, 128, n.L[9].W, 128, 256, H8b, 256, Gb, 256, Mp, GM(9));    // -> pre-activation grad of h8b
+        wgrad(c, t, n, 8, C8, kLdC8, Gb, 256, 256, 0, Mp, GM(9));
         // dL/dh8 = Gb . W8^T + Graw[:,3] * W11   (WT11 row 0 = the sigma head's column)
-        dgrad(c, Gb, 256, 256, n.L[8].W, 256, 256, C8, kLdC8, Ga, 256, Mp, Graw + 3, n.L[11].WT);
+        dgrad(c, Gb, 256, 256, n.L[8].W, 256, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[11].WT);
     }
-    wgrad(c, t, n, 7, H7, 256, Ga, 256, 256, 0, Mp);
-    dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp);
-    wgrad(c, t, n, 6, H6, 256, Gb, 256, 256, 0, Mp);
-    dgrad(c, Gb, 256, 256, n.L[6].W, 256, 256, H6, 256, Ga, 256, Mp);
-    wgrad(c, t, n, 5, H5, 256, Ga, 256, 256, 0, Mp);
-    dgrad(c, Ga, 256, 256, n.L[5].W, 256, 256, H5, 256, Gb, 256, Mp);
-    wgrad(c, t, n, 4, C4, kLdC4, Gb, 256, 256, 0, Mp);
-    dgrad(c, Gb, 256, 256, n.L[4].W, 256, 256, C4, kLdC4, Ga, 256, Mp);
+    wgrad(c, t, n, 7, H7, 256, Ga, 256, 256, 0, Mp, GM(1));
+    dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp, GM(2));
+    wgrad(c, t, n, 6, H6, 256, Gb, 256, 256, 0, Mp, GM(2));
+    dgrad(c, Gb, 256, 256, n.L[6].W, 256, 256, H6, 256, Ga, 256, Mp, GM(3));
+    wgrad(c, t, n, 5, H5, 256, Ga, 256, 256, 0, Mp, GM(3));
+    dgrad(c, Ga, 256, 256, n.L[5].W, 256, 256, H5, 256, Gb, 256, Mp, GM(4));
+    wgrad(c, t, n, 4, C4, kLdC4, Gb, 256, 256, 0, Mp, GM(4));
+    dgrad(c, Gb, 256, 256, n.L[4].W, 256, 256, C4, kLdC4, Ga, 256, Mp, GM(5));
     if (dx) dgrad_xyz(c, Gb, n.L[4].W + (size_t)256 * 256, dA0, Mp, false);     // skip connection's xyz rows
-    wgrad(c, t, n, 3, H3, 256, Ga, 256, 256, 0, Mp);
-    dgrad(c, Ga, 256, 256, n.L[3].W, 256, 256, H3, 256, Gb, 256, Mp);
-    wgrad(c, t, n, 2, H2, 256, Gb, 256, 256, 0, Mp);
-    dgrad(c, Gb, 256, 256, n.L[2].W, 256, 256, H2, 256, Ga, 256, Mp);
-    wgrad(c, t, n, 1, H1, 256, Ga, 256, 256, 0, Mp);
-    dgrad(c, Ga, 256, 256, n.L[1].W, 256, 256, H1, 256, Gb, 256, Mp);
-    wgrad(c, t, n, 0, C4 + 256, kLdC4, Gb, 256, 256, 0, Mp);
+    wgrad(c, t, n, 3, H3, 256, Ga, 256, 256, 0, Mp, GM(5));
+    dgrad(c, Ga, 256, 256, n.L[3].W, 256, 256, H3, 256, Gb, 256, Mp, GM(6));
+    wgrad(c, t, n, 2, H2, 256, Gb, 256, 256, 0, Mp, GM(6));
+    dgrad(c, Gb, 256, 256, n.L[2].W, 256, 256, H2, 256, Ga, 256, Mp, GM(7));
+    wgrad(c, t, n, 1, H1, 256, Ga, 256, 256, 0, Mp, GM(7));
+    dgrad(c, Ga, 256, 256, n.L[1].W, 256, 256, H1, 256, Gb, 256, Mp, GM(8));
+    wgrad(c, t, n, 0, C4 + 256, kLdC4, Gb, 256, 256, 0, Mp, GM(8));
     if (dx) {
         dgrad_xyz(c, Gb, n.L[0].W, dA0, Mp, true);
         launch_pe_bwd(dA0, o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
@@ -356,6 +367,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     r |= ensure(c, t->d_wext, dc.M * f);
     r |= ensure(c, t->d_zf, (fine ? df.M : 1) * f);
     r |= ensure(c, t->scal, 4 * f);
+    r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
     if (r) return r;
     float* scal = (float*)t->scal.p;
     float* Graw = (float*)t->Graw.p;
@@ -445,7 +457,7 @@ void train_free(nerf_ctx* c) {
         for (DevBuf* b : bs) free_buf(*b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
-                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal};
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax};
     for (DevBuf* b : bs) free_buf(*b);
     delete t;
     c->train = nullptr;
@@ -534,6 +546,9 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
     const char* fw = getenv("NERF_TRAIN_FORWARD");
     t->fused_forward = c->cfg.n_angles != 0 && !(fw && strcmp(fw, "gemm") == 0);
+    // weight gradients on the fp16 matrix cores (split operands, fp32-class) unless NERF_TRAIN_WGRAD=fp32
+    const char* wg = getenv("NERF_TRAIN_WGRAD");
+    t->wgrad_f16 = !(wg && strcmp(wg, "fp32") == 0);
     for (int w = 0; w < 2; ++w) {
         if (!c->net[w].loaded) continue;
         if (!t->net[w].present) {

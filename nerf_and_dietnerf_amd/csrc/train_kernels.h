@@ -29,6 +29,7 @@ struct GemmAbt {
     int n_valid;                // columns actually stored
     int accumulate;             // BWD_PLAIN: Out += result
     float alpha;
+    unsigned* gmax;             // BWD_MASK optional: atomicMax of the bits of max|Out| (for the split-fp16 weight gradient)
 };
 void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s);
 
@@ -38,8 +39,13 @@ struct GemmAtb {
     const float* G; int ldg; int N;     // N = columns of G used (multiple of 4)
     float* partial; int Kp; int Nw;     // partial: [splits][Kp + 1][Nw]
     long long M; int rows_per_split;    // multiple of 16
+    const unsigned* gmax;               // split-fp16 variant: bits of max|G| (written by G's producer); G is scaled to fp16 range
 };
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
+// same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
+// three MFMA passes, fp32 accumulation; G is pre-scaled by a power of two so that its largest entry sits at 2^14
+void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s);
+void launch_head_wgrad(const GemmAtb& g, hipStream_t s);   // N = 4 (the heads): VALU kernel, same partial layout
 
 // grad[blob layout] = sum over splits of partial (deterministic order)
 struct ReduceArgs {
@@ -64,7 +70,7 @@ void launch_mse(const float* rgb, const float* target, long long N, float* d_rgb
 void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
                           const float* d_w_ext, float* Graw, float* d_z, hipStream_t s);
 void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,
-                     long long M, float alpha, float* G9, hipStream_t s);
+                     long long M, float alpha, float* G9, unsigned* gmax, hipStream_t s);
 void launch_pe_bwd(const float* dA0, const float* o, const float* d, const float* z, long long N, int S, float* d_z,
                    hipStream_t s);
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,

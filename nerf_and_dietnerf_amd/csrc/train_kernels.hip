@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NERF_ABT
     abt_compute<WTM, WTN, LDA, LDB>(As[buf], Bs[buf], wm * WTM * 32, wn * WTN * 32, li, lh, acc);
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float vmax = 0.f;
 #pragma unroll
     for (int a = 0; a < WTM; ++a)
 #pragma unroll
@@ -197,12 +198,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NERF_ABT
                 } else if (EPI == EPI_BWD_MASK) {
                     if (g.r1a) v = fmaf(g.r1a[m * g.r1a_ld], r1b, v);
                     v = hmask[a][b][r] > 0.f ? v : g.alpha * v;
+                    vmax = fmaxf(vmax, fabsf(v));
                 } else {
                     if (g.accumulate) v += g.Out[m * g.ldo + n];
                 }
                 if (n < g.n_valid) g.Out[m * g.ldo + n] = v;
             }
         }
+    if (EPI == EPI_BWD_MASK && g.gmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        // 64 slots per buffer and a plain read first: same-address atomics from 32 k waves would serialise in L2
+        if (lane == 0) {
+            unsigned* slot = g.gmax + (blockIdx.x & 63);
+            const unsigned vb = __float_as_uint(vmax);               // non-negative floats order like their bits
+            if (vb > *slot) atomicMax(slot, vb);
+        }
+    }
 }
 
 template <int EPI>
@@ -343,6 +355,212 @@ void launch_gemm_atb(const GemmAtb& g, hipStream_t s) {
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
     const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
     hipLaunchKernelGGL(gemm_atb_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_atb_h: the weight-gradient GEMM on the fp16 matrix cores.  Both operands are split x = hi + lo (two fp16 values,
+// 22 significant bits) while they are staged, and each product is formed in three passes hi*lo + lo*hi + hi*hi of
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation -- the arithmetic of the render path's f16x3 kernel.  Gradients are tiny
+// (1e-5 and below), so G is multiplied by a power of two that puts its largest entry (tracked by its producer with an
+// atomicMax) at 2^14; the partial sums are divided by it again.  Staging: 128 threads per operand, each a 4 rows x 4
+// columns block (four global float4 loads), transposed in registers so that the 16 sample rows of a column land
+// contiguously: the MFMA operand of lane (column, half) is one ds_read_b128.  LDS: [plane][column][16 rows] fp16, 48-byte
+// column stride (conflict-free for the 64 x 16-byte operand reads).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+constexpr int kHColStride = 48;                       // bytes per column of a plane
+constexpr int kHPlane = 128 * kHColStride;            // 6144 B
+
+// hi = the top 11 significand bits (exact in fp16 for normal-range values), lo = v - hi rounded to fp16: two plain VALU ops
+// and one v_cvt_pk_f16_f32 per half pair (beside the fp16 MFMA, conversions are the expensive instructions).  Values
+// below the fp16 normal range (|v| < 2^-14, i.e. < 2^-28 of the largest entry after scaling) keep an absolute error
+// of 2^-25: irrelevant in sums dominated by entries ten orders of magnitude larger.
+__device__ __forceinline__ void split_pack2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+    const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
+    const h2v h = {(_Float16)h0, (_Float16)h1};
+    const h2v l = {(_Float16)(v0 - h0), (_Float16)(v1 - h1)};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_atb_h_kernel(const GemmAtb g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * kHPlane];    // planes: A hi, A lo, G hi, G lo
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kt_n = (g.Kp + 127) / 128, nt_n = (g.Nw + 127) / 128, T = kt_n * nt_n;
+    const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
+    int split = grp * 8 + rem % 8, tile = rem / 8;
+    if (grp * 8 + 8 > n_splits) {
+        const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
+        split = grp * 8 + r2 % left;
+        tile = r2 / left;
+    }
+    const int kb = (tile % kt_n) * 128, nb = (tile / kt_n) * 128;
+    const bool first_ktile = tile % kt_n == 0;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    // power-of-two scale of G: largest entry -> [2^14, 2^15)
+    unsigned mb = g.gmax ? g.gmax[lane] : 0u;                  // 64 slots per buffer (see the producers)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mb, o); mb = other > mb ? other : mb; }
+    int sexp = mb ? 127 + 14 - ((int)((mb >> 23) & 0xFF) - 127) : 127;
+    sexp = sexp < 1 ? 1 : sexp > 254 ? 254 : sexp;
+    const float gscale = __uint_as_float((unsigned)sexp << 23), ginv = 1.0f / gscale;
+    // staging role of this thread: operand (A: t < 128, G: t >= 128), rows 4 rg .. 4 rg + 3, columns 4 cg .. 4 cg + 3
+    const bool isG = t >= 128;
+    const int b = t & 127, rg = b & 3, cg = b >> 2;
+    const int ld = isG ? g.ldg : g.lda;
+    const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
+    const float* src = (isG ? g.G + nb : g.A + kb) + (ms + 4 * rg) * ld + 4 * cg;
+    const float mul = isG ? gscale : 1.0f;
+    const int wbase = (isG ? 2 : 0) * kHPlane + 4 * cg * kHColStride + rg * 8;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;      // column sums of the raw G block (bias gradient)
+
+    float4 r0 = zero4, r1 = zero4, r2 = zero4, r3 = zero4;
+#define ATBH_FETCH(ST)                                                                        \
+    if (on) {                                                                                 \
+        const float* q_ = src + (size_t)(ST) * 16 * ld;                                       \
+        r0 = *reinterpret_cast<const float4*>(q_);                                            \
+        r1 = *reinterpret_cast<const float4*>(q_ + ld);                                       \
+        r2 = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);                           \
+        r3 = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);                           \
+    }
+#define ATBH_COL(J, C0, C1, C2, C3, BUF)                                                      \
+    {                                                                                         \
+        uint32_t h01, l01, h23, l23;                                                          \
+        split_pack2((C0) * mul, (C1) * mul, h01, l01);                                        \
+        split_pack2((C2) * mul, (C3) * mul, h23, l23);                                        \
+        unsigned char* w_ = &lds[BUF][wbase + (J) * kHColStride];                             \
+        *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);                                 \
+        *reinterpret_cast<uint2*>(w_ + kHPlane) = make_uint2(l01, l23);                       \
+    }
+#define ATBH_PARK(BUF)                                                                        \
+    cs0 += (r0.x + r1.x) + (r2.x + r3.x); cs1 += (r0.y + r1.y) + (r2.y + r3.y);               \
+    cs2 += (r0.z + r1.z) + (r2.z + r3.z); cs3 += (r0.w + r1.w) + (r2.w + r3.w);               \
+    ATBH_COL(0, r0.x, r1.x, r2.x, r3.x, BUF)                                                  \
+    ATBH_COL(1, r0.y, r1.y, r2.y, r3.y, BUF)                                                  \
+    ATBH_COL(2, r0.z, r1.z, r2.z, r3.z, BUF)                                                  \
+    ATBH_COL(3, r0.w, r1.w, r2.w, r3.w, BUF)
+
+    auto compute = [&](int buf) {
+        const unsigned char* base = lds[buf];
+        h8v ah[2], al[2], gh[2], gl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ca = (wk * 64 + q * 32 + li) * kHColStride + 16 * lh;
+            const int cgd = (wn * 64 + q * 32 + li) * kHColStride + 16 * lh;
+            ah[q] = *reinterpret_cast<const h8v*>(base + ca);
+            al[q] = *reinterpret_cast<const h8v*>(base + kHPlane + ca);
+            gh[q] = *reinterpret_cast<const h8v*>(base + 2 * kHPlane + cgd);
+            gl[q] = *reinterpret_cast<const h8v*>(base + 3 * kHPlane + cgd);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gl[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], gh[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gh[c], acc[a][c], 0, 0, 0);
+            }
+    };
+
+    if (ms < me) {
+        const long long steps = (me - ms) / 16;
+        ATBH_FETCH(0)
+        ATBH_PARK(0)
+        __syncthreads();
+        int buf = 0;
+        for (long long st = 1; st < steps; ++st) {
+            ATBH_FETCH(st)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            ATBH_PARK(buf ^ 1)
+            __syncthreads();
+            buf ^= 1;
+        }
+        compute(buf);
+    }
+#undef ATBH_FETCH
+#undef ATBH_COL
+#undef ATBH_PARK
+
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = nb + wn * 64 + c * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + wk * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < g.Kp && n < g.Nw) part[(size_t)k * g.Nw + n] = acc[a][c][r] * ginv;
+            }
+        }
+    // bias gradient: column sums of the raw (unscaled) G rows of this slab; the four row groups of a column block are
+    // four neighbouring lanes
+    cs0 += __shfl_xor(cs0, 1); cs1 += __shfl_xor(cs1, 1); cs2 += __shfl_xor(cs2, 1); cs3 += __shfl_xor(cs3, 1);
+    cs0 += __shfl_xor(cs0, 2); cs1 += __shfl_xor(cs1, 2); cs2 += __shfl_xor(cs2, 2); cs3 += __shfl_xor(cs3, 2);
+    if (first_ktile && isG && rg == 0 && nb + 4 * cg < g.Nw) {
+        float* prow = part + (size_t)g.Kp * g.Nw + nb + 4 * cg;
+        prow[0] = cs0; prow[1] = cs1; prow[2] = cs2; prow[3] = cs3;
+    }
+}
+
+void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s) {
+    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
+    hipLaunchKernelGGL(gemm_atb_h_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_wgrad: weight gradients of the two heads (N = 4 columns of Graw): a (K x 4) result needs no matrix core.  One
+// workgroup per row slab, one thread per column of A; writes the same partial layout as gemm_atb (row Kp = column sums).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const GemmAtb g) {
+    const int split = blockIdx.x, t = threadIdx.x;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+    for (int k = t; k < g.Kp + 1; k += 256) {
+        const bool ones = k == g.Kp;                       // the extra row: column sums of G
+        const bool valid = ones || k < g.K;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (valid)
+            for (long long m = ms; m < me; m += 8) {       // slabs are multiples of 16 rows: 8 loads in flight
+                float av[8];
+                float4 gv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    gv[q] = *reinterpret_cast<const float4*>(g.G + (m + q) * g.ldg);
+                    av[q] = ones ? 1.0f : g.A[(m + q) * g.lda + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a0 = fmaf(av[q], gv[q].x, a0); a1 = fmaf(av[q], gv[q].y, a1);
+                    a2 = fmaf(av[q], gv[q].z, a2); a3 = fmaf(av[q], gv[q].w, a3);
+                }
+            }
+        float* o = part + (size_t)k * g.Nw;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    }
+}
+
+void launch_head_wgrad(const GemmAtb& g, hipStream_t s) {
+    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)splits), dim3(256), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,7 +774,7 @@ void launch_composite_bwd(const float* raw, const float* z, const float* T, long
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ Graw, const float* __restrict__ W9,
                                                        const float* __restrict__ H9, long long M, float alpha,
-                                                       float* __restrict__ G9) {
+                                                       float* __restrict__ G9, unsigned* __restrict__ gmax) {
     __shared__ float w[128 * 3];
     for (int i = threadIdx.x; i < 128 * 3; i += 256) w[i] = W9[(i / 3) * 32 + (i % 3)];
     __syncthreads();
@@ -576,13 +794,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
     out.x = ov[0]; out.y = ov[1]; out.z = ov[2]; out.w = ov[3];
     *reinterpret_cast<float4*>(G9 + m * 128 + j) = out;
+    if (gmax) {      // uniform per launch.  One slot check per workgroup: 65 k workgroups each polling per wave was 0.7 ms
+        __shared__ float wmax[4];
+        float vmax = fmaxf(fmaxf(fabsf(ov[0]), fabsf(ov[1])), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            unsigned* slot = gmax + (blockIdx.x & 63);
+            const unsigned vb = __float_as_uint(m4);
+            if (vb > *slot) atomicMax(slot, vb);
+        }
+    }
 }
 
 void launch_head_bwd(const float* Graw, const float* W9, const float* H9, long long M, float alpha, float* G9,
-                     hipStream_t s) {
+                     unsigned* gmax, hipStream_t s) {
     if (M <= 0) return;
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, s, Graw, W9, H9, M, alpha,
-                       G9);
+                       G9, gmax);
 }
 
 // ------------------------------------------------------------------------------------------------
