@@ -21,6 +21,7 @@ struct TLayer {
     int K_real, N_real, Kp, Np, rowmap;
     size_t w_off, b_off;           // offsets into the blob
     float *W, *WT, *bias;          // padded copies (device)
+    uint16_t *Whi, *Wlo;           // W split into fp16 hi / lo planes (data gradient on the fp16 cores)
 };
 
 struct TNet {
@@ -48,6 +49,7 @@ struct TrainState {
     TPass pass[2];
     DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal, gmax;
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
+    bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
@@ -88,7 +90,7 @@ int relayout_net(nerf_ctx* c, TNet& n) {
         RelayoutArgs a;
         a.w = n.blob + L.w_off; a.b = n.blob + L.b_off;
         a.K_real = L.K_real; a.N_real = L.N_real; a.Kp = L.Kp; a.Np = L.Np; a.rowmap = L.rowmap;
-        a.W = L.W; a.WT = L.WT; a.bias = L.bias;
+        a.W = L.W; a.WT = L.WT; a.bias = L.bias; a.Whi = L.Whi; a.Wlo = L.Wlo;
         launch_relayout(a, c->stream);
     }
     HIP_OK(hipGetLastError());
@@ -130,13 +132,16 @@ int init_net(nerf_ctx* c, TrainState* t, int which) {
     if (t->training)
         if (int r = alloc_optimizer(c, t, n)) return r;
     size_t mats = 0;
-    for (int l = 0; l < n.n_layers; ++l) mats += 2 * (size_t)n.L[l].Kp * n.L[l].Np + n.L[l].Np;
+    for (int l = 0; l < n.n_layers; ++l) mats += 3 * (size_t)n.L[l].Kp * n.L[l].Np + n.L[l].Np;   // W, WT, (Whi + Wlo), bias
     HIP_OK(hipMalloc((void**)&n.mats, mats * sizeof(float)));
     float* p = n.mats;
     for (int l = 0; l < n.n_layers; ++l) {
         TLayer& L = n.L[l];
         L.W = p; p += (size_t)L.Kp * L.Np;
         L.WT = p; p += (size_t)L.Kp * L.Np;
+        L.Whi = reinterpret_cast<uint16_t*>(p);
+        L.Wlo = L.Whi + (size_t)L.Kp * L.Np;
+        p += (size_t)L.Kp * L.Np;          // two half planes = one float plane
         L.bias = p; p += L.Np;
     }
     HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), nb, hipMemcpyHostToDevice, c->stream));
@@ -251,9 +256,18 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
 }
 
 void dgrad(nerf_ctx* c, const float* G, int ldg, int Kg, const float* Wrows, int ldb, int Nout, const float* H, int ldh,
-           float* Out, int ldo, long long Mp, unsigned* gmax_out, const float* r1a = nullptr, const float* r1b = nullptr) {
+           float* Out, int ldo, long long Mp, unsigned* gmax_out, const float* r1a = nullptr, const float* r1b = nullptr,
+           const TLayer* split = nullptr, const unsigned* gmax_in = nullptr) {
     GemmAbt g{};
     g.gmax = gmax_out;
+    if (split && gmax_in && Nout % 128 == 0 && Kg % 32 == 0) {     // fp16 matrix cores: W comes pre-split (rows 0.. of W)
+        g.A = G; g.lda = ldg; g.ldb = ldb; g.Out = Out; g.ldo = ldo;
+        g.M = Mp; g.N = Nout; g.K = Kg; g.H = H; g.ldh = ldh; g.r1a = r1a; g.r1a_ld = 4; g.r1b = r1b;
+        g.n_valid = Nout; g.alpha = c->cfg.leaky_relu_alpha;
+        g.Bhi = split->Whi; g.Blo = split->Wlo; g.gmax_in = gmax_in;
+        launch_gemm_abt_h(g, c->stream);
+        return;
+    }
     g.A = G; g.lda = ldg; g.Bt = Wrows; g.ldb = ldb; g.Out = Out; g.ldo = ldo;
     g.M = Mp; g.N = Nout; g.K = Kg; g.H = H; g.ldh = ldh; g.r1a = r1a; g.r1a_ld = 4; g.r1b = r1b;
     g.n_valid = Nout; g.alpha = c->cfg.leaky_relu_alpha;
@@ -284,39 +298,40 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     unsigned* gm = t->wgrad_f16 ? (unsigned*)t->gmax.p : nullptr;      // exact-fp32 weight gradients need no scale
     if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
     auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
+    auto DS = [&](int l) -> const TLayer* { return t->dgrad_f16 && gm ? &n.L[l] : nullptr; };   // pre-split W of layer l
     if (n.n_layers == 11) {
         wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
         launch_head_bwd(Graw, n.L[9].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, GM(0), c->stream);
         wgrad(c, t, n, 8, C8, kLdC8, G9, 128, 128, 0, Mp, GM(0));
         // dL/dh8 = G9 . W8[hidden rows]^T + Graw[:,3] * W10[hidden rows]   (WT10 row 0 = the sigma head's column)
-        dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[10].WT);
+        dgrad(c, G9, 128, 128, n.L[8].W, 128, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[10].WT, DS(8), GM(0));
     } else {
         float* H8b = (float*)p.H8b.p;
         wgrad(c, t, n, 10, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 11, C8, kLdC8, Graw, 4, 4, 3, Mp);
         launch_head_bwd(Graw, n.L[10].W, H9, Mp, c->cfg.leaky_relu_alpha, G9, GM(0), c->stream);
         wgrad(c, t, n, 9, H8b, 256, G9, 128, 128, 0, Mp, GM(0));
-        dgrad(c, G9, 128, 128, n.L[9].W, 128, 256, H8b, 256, Gb, 256, Mp, GM(9));    // -> pre-activation grad of h8b
+        dgrad(c, G9, 128, 128, n.L[9].W, 128, 256, H8b, 256, Gb, 256, Mp, GM(9), nullptr, nullptr, DS(9), GM(0));    // -> pre-activation grad of h8b
         wgrad(c, t, n, 8, C8, kLdC8, Gb, 256, 256, 0, Mp, GM(9));
         // dL/dh8 = Gb . W8^T + Graw[:,3] * W11   (WT11 row 0 = the sigma head's column)
-        dgrad(c, Gb, 256, 256, n.L[8].W, 256, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[11].WT);
+        dgrad(c, Gb, 256, 256, n.L[8].W, 256, 256, C8, kLdC8, Ga, 256, Mp, GM(1), Graw + 3, n.L[11].WT, DS(8), GM(9));
     }
     wgrad(c, t, n, 7, H7, 256, Ga, 256, 256, 0, Mp, GM(1));
-    dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp, GM(2));
+    dgrad(c, Ga, 256, 256, n.L[7].W, 256, 256, H7, 256, Gb, 256, Mp, GM(2), nullptr, nullptr, DS(7), GM(1));
     wgrad(c, t, n, 6, H6, 256, Gb, 256, 256, 0, Mp, GM(2));
-    dgrad(c, Gb, 256, 256, n.L[6].W, 256, 256, H6, 256, Ga, 256, Mp, GM(3));
+    dgrad(c, Gb, 256, 256, n.L[6].W, 256, 256, H6, 256, Ga, 256, Mp, GM(3), nullptr, nullptr, DS(6), GM(2));
     wgrad(c, t, n, 5, H5, 256, Ga, 256, 256, 0, Mp, GM(3));
-    dgrad(c, Ga, 256, 256, n.L[5].W, 256, 256, H5, 256, Gb, 256, Mp, GM(4));
+    dgrad(c, Ga, 256, 256, n.L[5].W, 256, 256, H5, 256, Gb, 256, Mp, GM(4), nullptr, nullptr, DS(5), GM(3));
     wgrad(c, t, n, 4, C4, kLdC4, Gb, 256, 256, 0, Mp, GM(4));
-    dgrad(c, Gb, 256, 256, n.L[4].W, 256, 256, C4, kLdC4, Ga, 256, Mp, GM(5));
+    dgrad(c, Gb, 256, 256, n.L[4].W, 256, 256, C4, kLdC4, Ga, 256, Mp, GM(5), nullptr, nullptr, DS(4), GM(4));
     if (dx) dgrad_xyz(c, Gb, n.L[4].W + (size_t)256 * 256, dA0, Mp, false);     // skip connection's xyz rows
     wgrad(c, t, n, 3, H3, 256, Ga, 256, 256, 0, Mp, GM(5));
-    dgrad(c, Ga, 256, 256, n.L[3].W, 256, 256, H3, 256, Gb, 256, Mp, GM(6));
+    dgrad(c, Ga, 256, 256, n.L[3].W, 256, 256, H3, 256, Gb, 256, Mp, GM(6), nullptr, nullptr, DS(3), GM(5));
     wgrad(c, t, n, 2, H2, 256, Gb, 256, 256, 0, Mp, GM(6));
-    dgrad(c, Gb, 256, 256, n.L[2].W, 256, 256, H2, 256, Ga, 256, Mp, GM(7));
+    dgrad(c, Gb, 256, 256, n.L[2].W, 256, 256, H2, 256, Ga, 256, Mp, GM(7), nullptr, nullptr, DS(2), GM(6));
     wgrad(c, t, n, 1, H1, 256, Ga, 256, 256, 0, Mp, GM(7));
-    dgrad(c, Ga, 256, 256, n.L[1].W, 256, 256, H1, 256, Gb, 256, Mp, GM(8));
+    dgrad(c, Ga, 256, 256, n.L[1].W, 256, 256, H1, 256, Gb, 256, Mp, GM(8), nullptr, nullptr, DS(1), GM(7));
     wgrad(c, t, n, 0, C4 + 256, kLdC4, Gb, 256, 256, 0, Mp, GM(8));
     if (dx) {
         dgrad_xyz(c, Gb, n.L[0].W, dA0, Mp, true);
@@ -549,6 +564,8 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // weight gradients on the fp16 matrix cores (split operands, fp32-class) unless NERF_TRAIN_WGRAD=fp32
     const char* wg = getenv("NERF_TRAIN_WGRAD");
     t->wgrad_f16 = !(wg && strcmp(wg, "fp32") == 0);
+    const char* dg = getenv("NERF_TRAIN_DGRAD");
+    t->dgrad_f16 = t->wgrad_f16 && !(dg && strcmp(dg, "fp32") == 0);     // needs the max tracking of the f16 path
     for (int w = 0; w < 2; ++w) {
         if (!c->net[w].loaded) continue;
         if (!t->net[w].present) {

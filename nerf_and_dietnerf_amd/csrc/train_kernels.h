@@ -30,8 +30,14 @@ struct GemmAbt {
     int accumulate;             // BWD_PLAIN: Out += result
     float alpha;
     unsigned* gmax;             // BWD_MASK optional: atomicMax of the bits of max|Out| (for the split-fp16 weight gradient)
+    // split-fp16 variant (launch_gemm_abt_h): Bt pre-split into fp16 hi / lo planes of the same shape; max|A| slots
+    const uint16_t* Bhi; const uint16_t* Blo;
+    const unsigned* gmax_in;
 };
 void launch_gemm_abt(int epi, bool narrow, const GemmAbt& g, hipStream_t s);
+// the data-gradient GEMM (EPI_BWD_MASK, 128-wide tiles) on the fp16 matrix cores: A (a gradient buffer, scaled by a power
+// of two from gmax_in) is split while it is staged, Bt comes pre-split; three MFMA passes, fp32 accumulation
+void launch_gemm_abt_h(const GemmAbt& g, hipStream_t s);
 
 // partial[split][k][n] = sum over the split's rows of A[m][k] * G[m][n]; row Kp of every split = column sums of G
 struct GemmAtb {
@@ -60,6 +66,7 @@ void launch_reduce_grad(const ReduceArgs& a, hipStream_t s);
 struct RelayoutArgs {
     const float* w; const float* b; int K_real, N_real, Kp, Np, rowmap;
     float* W; float* WT; float* bias;
+    uint16_t* Whi; uint16_t* Wlo;       // W split into fp16 hi / lo planes (same [Kp x Np] layout)
 };
 void launch_relayout(const RelayoutArgs& a, hipStream_t s);
 

@@ -526,6 +526,171 @@ void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_abt_h: the data-gradient GEMM  G_prev = (G . W^T [+ rank-1]) * LeakyReLU'(H)  on the fp16 matrix cores, same
+// arithmetic as gemm_atb_h: G is scaled to the fp16 range (its max comes from its producer) and split hi + lo while it is
+// staged (rows are k-contiguous: no transpose), W comes pre-split from the relayout kernel; three passes of
+// v_mfma_f32_32x32x16_f16, fp32 accumulation, then the usual epilogue on acc / scale.  k-step 32, 80-byte LDS rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAbhStride = 80;
+constexpr int kAbhPlane = 128 * kAbhStride;     // 10 240 B: 128 rows x (32 halfs + pad)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_abt_h_kernel(const GemmAbt g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * kAbhPlane];   // planes: A hi, A lo, B hi, B lo
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = g.N / 128;
+    const long long lin = blockIdx.x, grp = lin / (8 * n_tiles), rem = lin % (8 * n_tiles);
+    long long m_tile = grp * 8 + rem % 8;
+    int n_tile = (int)(rem / 8);
+    const long long m_tiles = g.M / 128;
+    if (grp * 8 + 8 > m_tiles) {
+        const long long base = grp * 8 * n_tiles, r2 = lin - base, left = m_tiles - grp * 8;
+        m_tile = grp * 8 + r2 % left;
+        n_tile = (int)(r2 / left);
+    }
+    const long long m0 = m_tile * 128;
+    const int n0 = n_tile * 128;
+    unsigned mb = g.gmax_in ? g.gmax_in[lane] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mb, o); mb = other > mb ? other : mb; }
+    int sexp = mb ? 127 + 14 - ((int)((mb >> 23) & 0xFF) - 127) : 127;
+    sexp = sexp < 1 ? 1 : sexp > 254 ? 254 : sexp;
+    const float gscale = __uint_as_float((unsigned)sexp << 23), ginv = 1.0f / gscale;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    float hmask[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = n0 + (wn * 2 + c) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                hmask[a][c][r] = g.H[m * g.ldh + n];
+            }
+        }
+
+    // staging slots: A tile 128 rows x 32 k fp32 = 1024 float4 (4 per thread); B planes 128 rows x 32 halfs = 512 x 16 B each
+    const int arow = t >> 3, akq = t & 7;            // + 32 i rows
+    const float* ap = g.A + (m0 + arow) * g.lda + 4 * akq;
+    const size_t a32 = (size_t)32 * g.lda;
+    const int brow = t >> 2, bq = t & 3;             // + 64 i rows
+    const uint16_t* bph = g.Bhi + (size_t)(n0 + brow) * g.ldb + 8 * bq;
+    const uint16_t* bpl = g.Blo + (size_t)(n0 + brow) * g.ldb + 8 * bq;
+    const size_t b64 = (size_t)64 * g.ldb;
+    float4 ra0, ra1, ra2, ra3;
+    uint4 bh0, bh1, bl0, bl1;
+#define ABH_FETCH(K0)                                                                         \
+    ra0 = *reinterpret_cast<const float4*>(ap + (K0));                                        \
+    ra1 = *reinterpret_cast<const float4*>(ap + a32 + (K0));                                  \
+    ra2 = *reinterpret_cast<const float4*>(ap + 2 * a32 + (K0));                              \
+    ra3 = *reinterpret_cast<const float4*>(ap + 3 * a32 + (K0));                              \
+    bh0 = *reinterpret_cast<const uint4*>(bph + (K0));                                        \
+    bh1 = *reinterpret_cast<const uint4*>(bph + b64 + (K0));                                  \
+    bl0 = *reinterpret_cast<const uint4*>(bpl + (K0));                                        \
+    bl1 = *reinterpret_cast<const uint4*>(bpl + b64 + (K0));
+#define ABH_A(R, I, BUF)                                                                      \
+    {                                                                                         \
+        uint32_t h01, l01, h23, l23;                                                          \
+        split_pack2((R).x * gscale, (R).y * gscale, h01, l01);                                \
+        split_pack2((R).z * gscale, (R).w * gscale, h23, l23);                                \
+        unsigned char* w_ = &lds[BUF][(arow + 32 * (I)) * kAbhStride + akq * 8];              \
+        *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);                                 \
+        *reinterpret_cast<uint2*>(w_ + kAbhPlane) = make_uint2(l01, l23);                     \
+    }
+#define ABH_PARK(BUF)                                                                         \
+    ABH_A(ra0, 0, BUF) ABH_A(ra1, 1, BUF) ABH_A(ra2, 2, BUF) ABH_A(ra3, 3, BUF)               \
+    *reinterpret_cast<uint4*>(&lds[BUF][2 * kAbhPlane + brow * kAbhStride + bq * 16]) = bh0;  \
+    *reinterpret_cast<uint4*>(&lds[BUF][2 * kAbhPlane + (brow + 64) * kAbhStride + bq * 16]) = bh1; \
+    *reinterpret_cast<uint4*>(&lds[BUF][3 * kAbhPlane + brow * kAbhStride + bq * 16]) = bl0;  \
+    *reinterpret_cast<uint4*>(&lds[BUF][3 * kAbhPlane + (brow + 64) * kAbhStride + bq * 16]) = bl1;
+
+    auto compute = [&](int buf) {
+        const unsigned char* base = lds[buf];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ra = (wm * 64 + q * 32 + li) * kAbhStride + ks * 32 + 16 * lh;
+                const int rb = (wn * 64 + q * 32 + li) * kAbhStride + ks * 32 + 16 * lh;
+                ah[q] = *reinterpret_cast<const h8v*>(base + ra);
+                al[q] = *reinterpret_cast<const h8v*>(base + kAbhPlane + ra);
+                bh[q] = *reinterpret_cast<const h8v*>(base + 2 * kAbhPlane + rb);
+                bl[q] = *reinterpret_cast<const h8v*>(base + 3 * kAbhPlane + rb);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[c], acc[a][c], 0, 0, 0);
+                }
+        }
+    };
+
+    ABH_FETCH(0)
+    ABH_PARK(0)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 32; k0 < g.K; k0 += 32) {
+        ABH_FETCH(k0)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        ABH_PARK(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
+    }
+    compute(buf);
+#undef ABH_FETCH
+#undef ABH_A
+#undef ABH_PARK
+
+    float vmax = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = n0 + (wn * 2 + c) * 32 + li;
+            const float r1b = g.r1a ? g.r1b[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[a][c][r] * ginv;
+                if (g.r1a) v = fmaf(g.r1a[m * g.r1a_ld], r1b, v);
+                v = hmask[a][c][r] > 0.f ? v : g.alpha * v;
+                vmax = fmaxf(vmax, fabsf(v));
+                g.Out[m * g.ldo + n] = v;
+            }
+        }
+    if (g.gmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) {
+            unsigned* slot = g.gmax + (blockIdx.x & 63);
+            const unsigned vb = __float_as_uint(vmax);
+            if (vb > *slot) atomicMax(slot, vb);
+        }
+    }
+}
+
+void launch_gemm_abt_h(const GemmAbt& g, hipStream_t s) {
+    if (g.M <= 0) return;
+    hipLaunchKernelGGL(gemm_abt_h_kernel, dim3((unsigned)((g.M / 128) * (g.N / 128))), dim3(256), 0, s, g);
+}
+
+// ------------------------------------------------------------------------------------------------
 // head_wgrad: weight gradients of the two heads (N = 4 columns of Graw): a (K x 4) result needs no matrix core.  One
 // workgroup per row slab, one thread per column of A; writes the same partial layout as gemm_atb (row Kp = column sums).
 // ------------------------------------------------------------------------------------------------
@@ -603,6 +768,12 @@ __global__ void relayout_kernel(const RelayoutArgs a) {
     const float v = valid ? a.w[(size_t)kb * a.N_real + n] : 0.f;
     a.W[(size_t)kt * a.Np + n] = v;
     a.WT[(size_t)n * a.Kp + kt] = v;
+    if (a.Whi) {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        a.Whi[(size_t)kt * a.Np + n] = __builtin_bit_cast(uint16_t, hi);
+        a.Wlo[(size_t)kt * a.Np + n] = __builtin_bit_cast(uint16_t, lo);
+    }
     if (kt == 0) a.bias[n] = n < a.N_real ? a.b[n] : 0.f;
 }
 
