@@ -230,12 +230,15 @@ def main():
         model.ctx.train_end()
         tf_tr = 3 * n_tr * (SC + SF) * FLOPS_PER_ROW / e_tr / 1e12
         train = {"metric": "train_step (NeRF.train_step: coarse+fine forward, backward incl. sampler, Adam)",
-                 "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f32",
+                 "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                  "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
                  "loss_finite": bool(m_tr["loss"] == m_tr["loss"]),
-                 "roofline": {"bound": "mfma", "kernel": "gemm_abt / gemm_atb (layer-wise fp32 MFMA GEMMs), whole step",
-                              "achieved": tf_tr, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
-                              "frac": tf_tr / PEAK_TFLOPS["f32"],
+                 "roofline": {"bound": "mfma",
+                              "kernel": "whole step: mlp_f16x3_stash_kernel (fused forward) + gemm_abt_h / gemm_atb_h "
+                                        "(data / weight gradients), all 3-pass split-fp16 MFMA with fp32 accumulation",
+                              "achieved": tf_tr, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
+                              "frac": tf_tr / PEAK_TFLOPS["f16x3"], "frac_vs_fp32_matrix_peak": tf_tr / PEAK_TFLOPS["f32"],
+                              "mfma_passes_per_product": 3,
                               "flops": "3 x forward GEMM flops (forward, data gradient, weight gradient)"}}
 
     if rank == 0:
