@@ -240,7 +240,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
     g.partial = (float*)t->partial.p; g.Kp = L.Kp; g.Nw = Ncols; g.M = Mp;
     // the heads' (K x 4) results come from a VALU kernel that wants many small slabs; the GEMMs use kTrainSplits
-    const int want_splits = Ncols == 4 ? 256 : kTrainSplits;
+    const int want_splits = Ncols == 4 ? 1024 : kTrainSplits;
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 15) / 16 * 16;
     g.rows_per_split = (int)rps;
