@@ -10,9 +10,12 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KINDS = (("gemm_abt_kernel<2, 2, 2, 2, 0>", "gemm_abt forward (bias + LeakyReLU)"),
-         ("gemm_abt_kernel<2, 2, 2, 2, 2>", "gemm_abt data gradient (LeakyReLU' mask)"),
-         ("gemm_atb_kernel", "gemm_atb weight gradient"))
+KINDS = (("mlp_f16x3_stash_kernel", "fused forward with activation stash (3-pass split fp16)"),
+         ("gemm_abt_h_kernel", "gemm_abt_h data gradient (3-pass split fp16)"),
+         ("gemm_atb_h_kernel", "gemm_atb_h weight gradient (3-pass split fp16)"),
+         ("gemm_abt_kernel<2, 2, 2, 2, 0>", "gemm_abt forward, exact fp32 (xyz-only network / NERF_TRAIN_FORWARD=gemm)"),
+         ("gemm_abt_kernel<2, 2, 2, 2, 2>", "gemm_abt data gradient, exact fp32 (NERF_TRAIN_DGRAD=fp32)"),
+         ("gemm_atb_kernel", "gemm_atb weight gradient, exact fp32 (NERF_TRAIN_WGRAD=fp32)"))
 
 
 def main():
@@ -39,7 +42,7 @@ def main():
         o = {"launches": len(durs[kind]), "avg_launch_us": t * 1e6}
         if cyc:
             o["clock_ghz"] = cyc / t / 1e9 if t else None
-            o["mfma_util"] = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc
+            o["mfma_util"] = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc   # 1024 SIMDs
         if a.get("SQ_WAVE_CYCLES"):
             o["wait_any_frac"] = a.get("SQ_WAIT_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
             o["wait_inst_frac"] = a.get("SQ_WAIT_INST_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
