@@ -50,6 +50,7 @@ struct TrainState {
     DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal, gmax;
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
+    bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
@@ -240,13 +241,15 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
     g.partial = (float*)t->partial.p; g.Kp = L.Kp; g.Nw = Ncols; g.M = Mp;
     // the heads' (K x 4) results come from a VALU kernel that wants many small slabs; the GEMMs use kTrainSplits
-    const int want_splits = Ncols == 4 ? 1024 : kTrainSplits;
+    const bool f16 = t->wgrad_f16 && gmax && Ncols >= 128;
+    const bool wide = f16 && t->wgrad_wide && Ncols >= 256;
+    const int want_splits = Ncols == 4 ? 1024 : wide ? kTrainSplitsWide : kTrainSplits;
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 15) / 16 * 16;
     g.rows_per_split = (int)rps;
     g.gmax = gmax;
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
-    else if (t->wgrad_f16 && gmax && Ncols >= 128) launch_gemm_atb_h(g, c->stream);
+    else if (f16) launch_gemm_atb_h(g, c->stream, wide);
     else launch_gemm_atb(g, c->stream);
     ReduceArgs r{};
     r.partial = g.partial; r.Kp = L.Kp; r.Nw = Ncols; r.splits = (int)((Mp + rps - 1) / rps);
@@ -377,7 +380,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     r |= ensure(c, t->G9, Mmax * 128 * f);
     r |= ensure(c, t->Graw, Mmax * 4 * f);
     r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
-    r |= ensure(c, t->partial, (size_t)kTrainSplits * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->partial, (size_t)kTrainSplitsWide * (kLdC4 + 1) * 256 * f);
     r |= ensure(c, t->d_rgb, N * 3 * f);
     r |= ensure(c, t->d_wext, dc.M * f);
     r |= ensure(c, t->d_zf, (fine ? df.M : 1) * f);
@@ -564,6 +567,8 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // weight gradients on the fp16 matrix cores (split operands, fp32-class) unless NERF_TRAIN_WGRAD=fp32
     const char* wg = getenv("NERF_TRAIN_WGRAD");
     t->wgrad_f16 = !(wg && strcmp(wg, "fp32") == 0);
+    const char* ww = getenv("NERF_TRAIN_WGRAD_TILE");
+    t->wgrad_wide = !(ww && strcmp(ww, "128") == 0);
     const char* dg = getenv("NERF_TRAIN_DGRAD");
     t->dgrad_f16 = t->wgrad_f16 && !(dg && strcmp(dg, "fp32") == 0);     // needs the max tracking of the f16 path
     for (int w = 0; w < 2; ++w) {

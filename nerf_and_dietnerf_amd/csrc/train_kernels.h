@@ -12,6 +12,7 @@ constexpr int kLdC8 = 288;    // [h8 (256) | dir_enc (24 or 16) | 0-pad to 32]  
 constexpr int kXyzPad = 64;
 constexpr int kDirPad = 32;
 constexpr int kTrainSplits = 128;   // row slabs of the weight-gradient reduction
+constexpr int kTrainSplitsWide = 256;   // ... with the 256 x 256 tile (one tile per slab for a 256 x 256 layer)
 
 enum { EPI_FWD_LEAKY = 0, EPI_FWD_LINEAR = 1, EPI_BWD_MASK = 2, EPI_BWD_PLAIN = 3 };
 
@@ -50,7 +51,7 @@ struct GemmAtb {
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
 // three MFMA passes, fp32 accumulation; G is pre-scaled by a power of two so that its largest entry sits at 2^14
-void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s);
+void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide = false);   // wide: 256 x 256 tile, 512 threads
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s);   // N = 4 (the heads): VALU kernel, same partial layout
 
 // grad[blob layout] = sum over splits of partial (deterministic order)

@@ -370,7 +370,6 @@ void launch_gemm_atb(const GemmAtb& g, hipStream_t s) {
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 constexpr int kHColStride = 48;                       // bytes per column of a plane
-constexpr int kHPlane = 128 * kHColStride;            // 6144 B
 
 // hi = the top 11 significand bits (exact in fp16 for normal-range values), lo = v - hi rounded to fp16: two plain VALU ops
 // and one v_cvt_pk_f16_f32 per half pair (beside the fp16 MFMA, conversions are the expensive instructions).  Values
@@ -384,12 +383,17 @@ __device__ __forceinline__ void split_pack2(float v0, float v1, uint32_t& hi, ui
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_atb_h_kernel(const GemmAtb g) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * kHPlane];    // planes: A hi, A lo, G hi, G lo
+// W = tile width and height (128: four waves of 64 x 64; 256: eight waves of 128 x 64, A and G each read once per slab)
+template <int W>
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_h_kernel(const GemmAtb g) {
+    constexpr int kPl = W * kHColStride;          // bytes per plane
+    constexpr int WNW = W / 64;                   // waves along n (2 or 4); two along k
+    constexpr int KTL = W / 64;                   // 32-row k tiles per wave (2 or 4); two n tiles per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * kPl];    // planes: A hi, A lo, G hi, G lo
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wk = wave / WNW, wn = wave % WNW;
     const int li = lane & 31, lh = lane >> 5;
-    const int kt_n = (g.Kp + 127) / 128, nt_n = (g.Nw + 127) / 128, T = kt_n * nt_n;
+    const int kt_n = (g.Kp + W - 1) / W, nt_n = (g.Nw + W - 1) / W, T = kt_n * nt_n;
     const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
     const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
     int split = grp * 8 + rem % 8, tile = rem / 8;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         split = grp * 8 + r2 % left;
         tile = r2 / left;
     }
-    const int kb = (tile % kt_n) * 128, nb = (tile / kt_n) * 128;
+    const int kb = (tile % kt_n) * W, nb = (tile / kt_n) * W;
     const bool first_ktile = tile % kt_n == 0;
     const long long ms = (long long)split * g.rows_per_split;
     const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
@@ -409,19 +413,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     int sexp = mb ? 127 + 14 - ((int)((mb >> 23) & 0xFF) - 127) : 127;
     sexp = sexp < 1 ? 1 : sexp > 254 ? 254 : sexp;
     const float gscale = __uint_as_float((unsigned)sexp << 23), ginv = 1.0f / gscale;
-    // staging role of this thread: operand (A: t < 128, G: t >= 128), rows 4 rg .. 4 rg + 3, columns 4 cg .. 4 cg + 3
-    const bool isG = t >= 128;
-    const int b = t & 127, rg = b & 3, cg = b >> 2;
+    // staging role of this thread: operand (A: t < W, G: t >= W), rows 4 rg .. 4 rg + 3, columns 4 cg .. 4 cg + 3
+    const bool isG = t >= W;
+    const int b = t & (W - 1), rg = b & 3, cg = b >> 2;
     const int ld = isG ? g.ldg : g.lda;
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     const float* src = (isG ? g.G + nb : g.A + kb) + (ms + 4 * rg) * ld + 4 * cg;
     const float mul = isG ? gscale : 1.0f;
-    const int wbase = (isG ? 2 : 0) * kHPlane + 4 * cg * kHColStride + rg * 8;
+    const int wbase = (isG ? 2 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    f32x16 acc[2][2];
+    f32x16 acc[KTL][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KTL; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         split_pack2((C2) * mul, (C3) * mul, h23, l23);                                        \
         unsigned char* w_ = &lds[BUF][wbase + (J) * kHColStride];                             \
         *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);                                 \
-        *reinterpret_cast<uint2*>(w_ + kHPlane) = make_uint2(l01, l23);                       \
+        *reinterpret_cast<uint2*>(w_ + kPl) = make_uint2(l01, l23);                       \
     }
 #define ATBH_PARK(BUF)                                                                        \
     cs0 += (r0.x + r1.x) + (r2.x + r3.x); cs1 += (r0.y + r1.y) + (r2.y + r3.y);               \
@@ -456,18 +460,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     auto compute = [&](int buf) {
         const unsigned char* base = lds[buf];
-        h8v ah[2], al[2], gh[2], gl[2];
+        h8v ah[KTL], al[KTL], gh[2], gl[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int ca = (wk * 64 + q * 32 + li) * kHColStride + 16 * lh;
-            const int cgd = (wn * 64 + q * 32 + li) * kHColStride + 16 * lh;
+        for (int q = 0; q < KTL; ++q) {
+            const int ca = (wk * (W / 2) + q * 32 + li) * kHColStride + 16 * lh;
             ah[q] = *reinterpret_cast<const h8v*>(base + ca);
-            al[q] = *reinterpret_cast<const h8v*>(base + kHPlane + ca);
-            gh[q] = *reinterpret_cast<const h8v*>(base + 2 * kHPlane + cgd);
-            gl[q] = *reinterpret_cast<const h8v*>(base + 3 * kHPlane + cgd);
+            al[q] = *reinterpret_cast<const h8v*>(base + kPl + ca);
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 2; ++q) {
+            const int cgd = (wn * 64 + q * 32 + li) * kHColStride + 16 * lh;
+            gh[q] = *reinterpret_cast<const h8v*>(base + 2 * kPl + cgd);
+            gl[q] = *reinterpret_cast<const h8v*>(base + 3 * kPl + cgd);
+        }
+#pragma unroll
+        for (int a = 0; a < KTL; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gl[c], acc[a][c], 0, 0, 0);
@@ -499,13 +506,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KTL; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int n = nb + wn * 64 + c * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = kb + wk * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int k = kb + wk * (W / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (k < g.Kp && n < g.Nw) part[(size_t)k * g.Nw + n] = acc[a][c][r] * ginv;
             }
         }
@@ -519,10 +526,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 }
 
-void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s) {
+void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
-    hipLaunchKernelGGL(gemm_atb_h_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+    if (wide) {
+        const int tiles = ((g.Kp + 255) / 256) * ((g.Nw + 255) / 256);
+        hipLaunchKernelGGL(gemm_atb_h_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, s, g);
+    } else {
+        const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
+        hipLaunchKernelGGL(gemm_atb_h_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
