@@ -128,3 +128,36 @@ def test_path_video_pose_interpolation(golden_ckpt):
     np.testing.assert_allclose(tour[29], poses[0], atol=2e-6)                            # closed
     rot = N.get_rotation_matrix_from_source_to_dest_mats(a[:3, :3], b[:3, :3])
     np.testing.assert_allclose(rot[:3, :3] @ a[:3, :3].astype(np.float64), b[:3, :3], atol=1e-6)
+
+
+def test_ray_dataset_batches_and_rank_shares():
+    """RayDataset (the reference's shuffle + batch of src/UtilsNeuralRadianceField.py:135-161, rays resident in
+    memory): every ray exactly once per epoch, last batch smaller, a new order every epoch, and the data-parallel
+    shares of one batch are disjoint and complete (so averaged shard gradients = the batch gradient)."""
+    import torch
+    from nerf_and_dietnerf_amd.dataset import RayDataset
+    n = 1000
+    ids = torch.arange(n, dtype=torch.float32)
+    orig = ids[:, None].expand(n, 4).contiguous()
+    ds = RayDataset(orig, orig * 2, ids[:, None].expand(n, 3).contiguous(), batch_size=256, seed=5)
+    assert ds.n_rays == n and len(ds) == 4
+    epochs = []
+    for _ in range(2):
+        seen = []
+        sizes = []
+        for o, d, rgb in ds:
+            assert torch.equal(d, o * 2) and torch.equal(rgb[:, 0], o[:, 0])      # the three tensors stay aligned
+            sizes.append(o.shape[0])
+            seen.append(o[:, 0])
+        assert sizes == [256, 256, 256, 232]
+        seen = torch.cat(seen)
+        assert torch.equal(torch.sort(seen).values, ids)
+        epochs.append(seen)
+    assert not torch.equal(epochs[0], epochs[1])                                   # reshuffled every epoch
+    # two ranks, same seed and epoch: disjoint halves of every batch
+    r0 = RayDataset(orig, orig, orig[:, :3].contiguous(), 256, seed=5, rank=0, world=2)
+    r1 = RayDataset(orig, orig, orig[:, :3].contiguous(), 256, seed=5, rank=1, world=2)
+    full = RayDataset(orig, orig, orig[:, :3].contiguous(), 256, seed=5)
+    for (a, _, _), (b, _, _), (f, _, _) in zip(r0, r1, full):
+        both = torch.cat([a[:, 0], b[:, 0]])
+        assert both.numel() == f.shape[0] and torch.equal(torch.sort(both).values, torch.sort(f[:, 0]).values)
