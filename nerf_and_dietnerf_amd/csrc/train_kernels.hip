@@ -1064,12 +1064,13 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sample_pdf_bwd_kernel(
     const long long ray = (long long)blockIdx.x * kBwdWaves + wave;
     if (ray >= N) return;
     const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3;
-    const int per_wave = 4 * S4 + 6 * Sf4 + 4;
+    const int per_wave = 5 * S4 + 6 * Sf4 + 4;
     float* cdf = lds + wave * per_wave;
     float* zc = cdf + S4;
     float* wv = zc + S4;
     float* dcdf = wv + S4;
-    float* zn = dcdf + S4;
+    float* dcdf_hi = dcdf + S4;
+    float* zn = dcdf_hi + S4;
     float* span = zn + Sf4;       // z_hi - z_lo
     float* tt = span + Sf4;
     float* den = tt + Sf4;        // clamped denominators are stored negated
@@ -1155,34 +1156,41 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sample_pdf_bwd_kernel(
     for (int k = lane; k < Sf; k += 64, ++nk) { zn[k] = dlo_r[nk]; span[k] = dhi_r[nk]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // The +-(d_t t / den) pairs that a sample sends to its two bins are 1e5 times larger than what survives after the
+    // reverse cumulative sum: the sums run in double so that they cancel exactly (a per-ray kernel: the cost is nil).
     for (int s = lane; s < S; s += 64) {
-        float acc = 0.f;
+        double acc = 0.0;
         for (int k = 0; k < Sf; ++k) {
-            if (ilo[k] == s) acc += zn[k];
-            if (ihi[k] == s) acc += span[k];
+            if (ilo[k] == s) acc += (double)zn[k];
+            if (ihi[k] == s) acc += (double)span[k];
         }
-        dcdf[s] = acc;
+        dcdf[s] = (float)acc;
+        dcdf_hi[s] = (float)(acc - (double)(float)acc);      // keep the rounding remainder for the scan
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        float run = 0.f, dot = 0.f;
+        double run = 0.0, dot = 0.0;
         for (int s = S - 1; s >= 0; --s) {     // cumsum backward = reverse cumsum
-            run += dcdf[s];
-            dcdf[s] = run;
-            dot = fmaf(run, wv[s], dot);
+            run += (double)dcdf[s] + (double)dcdf_hi[s];
+            dcdf[s] = (float)run;
+            dcdf_hi[s] = (float)(run - (double)(float)run);
+            dot += run * (double)wv[s];
         }
-        scal[1] = dot;
+        scal[1] = (float)dot;
+        scal[2] = (float)(dot - (double)(float)dot);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float D = scal[0], dot = scal[1];
-    for (int s = lane; s < S; s += 64) d_w[ray * S + s] = dcdf[s] / D - dot / (D * D);
+    // d_w = (dpdf - sum_i dpdf_i pdf_i) / D is again a difference of nearly equal large numbers: double
+    const double D = (double)scal[0], dot = (double)scal[1] + (double)scal[2];
+    for (int s = lane; s < S; s += 64)
+        d_w[ray * S + s] = (float)(((double)dcdf[s] + (double)dcdf_hi[s]) / D - dot / (D * D));
 }
 
 size_t sample_pdf_bwd_lds_bytes(int S, int Sf) {
     const int S4 = (S + 3) & ~3, Sf4 = (Sf + 3) & ~3;
-    return (size_t)kBwdWaves * (4 * S4 + 6 * Sf4 + 4) * sizeof(float);
+    return (size_t)kBwdWaves * (5 * S4 + 6 * Sf4 + 4) * sizeof(float);
 }
 
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,

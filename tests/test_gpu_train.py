@@ -442,3 +442,44 @@ def test_train_step_with_one_rank_communicator(oracle, golden_ckpt):
     assert res[0][0] == res[1][0]
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def test_fp16_core_trainer_equals_exact_fp32_trainer_at_full_size(oracle, golden_ckpt, capsys, monkeypatch):
+    """The default trainer forms every product on the fp16 matrix cores with split operands; the exact-fp32 MFMA path
+    stays behind NERF_TRAIN_FORWARD / NERF_TRAIN_WGRAD / NERF_TRAIN_DGRAD.  On a batch far too large for the CPU oracle
+    (1024 rays x (64 + 128) samples) the two must give the same loss and the same gradients to fp32-class accuracy.
+    Compared with the sampler term off: through the sampler a single LeakyReLU sign flip in the fine pass (the two
+    forwards differ by ~1e-6, and ~1e2 of 3e7 pre-activations per layer sit that close to zero) moves one ray's whole
+    contribution to the coarse gradient -- with the term on, only the direction is pinned."""
+    p = _problem(oracle, golden_ckpt, n=64, sc=8, sf=8, seed=21)           # only for weights / near / far
+    o, d, rng = _rays(oracle, 1024, 17, hw=64)
+    tgt = rng.random((1024, 3), dtype=np.float32)
+    res = {}
+    for sg in (False, True):
+        for mode in ("fp32", "f16"):
+            if mode == "fp32":
+                monkeypatch.setenv("NERF_TRAIN_FORWARD", "gemm")
+                monkeypatch.setenv("NERF_TRAIN_WGRAD", "fp32")
+                monkeypatch.setenv("NERF_TRAIN_DGRAD", "fp32")
+            else:
+                for k in ("NERF_TRAIN_FORWARD", "NERF_TRAIN_WGRAD", "NERF_TRAIN_DGRAD"):
+                    monkeypatch.delenv(k, raising=False)
+            ctx = _ctx(p)
+            ctx.train_begin(5e-4, sampler_gradient=sg)
+            res[(sg, mode)] = ctx.train_gradients(o, d, tgt, 64, 128, seed=3)
+            ctx.close()
+    lines = []
+    for sg in (False, True):
+        (m32, gc32, gf32), (m16, gc16, gf16) = res[(sg, "fp32")], res[(sg, "f16")]
+        ec, ef = _relerr(gc16, gc32.astype(np.float64)), _relerr(gf16, gf32.astype(np.float64))
+        cc, cf = _cos(gc16, gc32.astype(np.float64)), _cos(gf16, gf32.astype(np.float64))
+        lines.append(f"sampler term {'on ' if sg else 'off'}: loss {m16['loss']:.8f} vs {m32['loss']:.8f}; max gradient "
+                     f"difference / max|g|: coarse {ec:.2e}, fine {ef:.2e}; cosine {cc:.7f}, {cf:.7f}")
+        assert abs(m16["loss"] - m32["loss"]) <= 2e-6 * m32["loss"]
+        assert ef <= 5e-3 and cf > 0.99999
+        if not sg:
+            assert ec <= 5e-3 and cc > 0.99999
+        else:
+            assert cc > 0.999
+    with capsys.disabled():
+        print("\n[fp16-core vs exact-fp32 trainer, 1024 rays x 192] " + "\n    ".join(lines))
