@@ -17,6 +17,8 @@ from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
                        poses_avg, recenter_poses, spherify_poses)
 from .video import (get_c2w_matrices_between_2_c2w_with_stretch, get_path_c2w_matrices,
+                    get_l_to_r_c2w_matrices_to_render, get_path_c2w_matrices_to_render,
+                    get_sphere_c2w_matrices_to_render,
                     get_rotation_matrix_from_source_to_dest_mats, interpolation_type_slerp_for_c2w,
                     slerp_rotation_matrix, get_l_to_r_c2w_matrices, get_sphere_matrices, get_sphere_matrix, histogram_equalize_depth,
                     render_video)

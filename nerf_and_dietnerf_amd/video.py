@@ -142,6 +142,55 @@ def get_rotation_matrix_from_source_to_dest_mats(source_mat: np.ndarray, dest_ma
 
 
 # ---------------------------------------------------------------------------------------------
+# the three camera tours of ExecutionRun (src/ExecutionRun.py:358-437).  The reference decides between its
+# "spherical" and "forward-facing" branches with a randomised scene analysis (RANSAC point of interest,
+# src/UtilsCV.py:440-464); that analysis is a pose utility outside this package, so its two results
+# (`is_spherical_dataset`, `estimated_intersection`) are arguments here.
+# ---------------------------------------------------------------------------------------------
+def get_l_to_r_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: int, fps_render_video: int,
+                                      is_spherical_dataset: bool, seconds: int = 5) -> np.ndarray:
+    """src/ExecutionRun.py:358-377: a 5 s slide along x.  Spherical datasets: the slide is taken in the test
+    view's frame (its rotation, position ``t_test - x``); otherwise it is placed at the average pose."""
+    poses = np.asarray(camera_poses, np.float64)
+    mats = get_l_to_r_c2w_matrices(int(fps_render_video) * seconds).astype(np.float64)
+    if is_spherical_dataset:
+        mats[:, :3, 3] = poses[test_img_idx][:3, 3] - mats[:, :3, 3]
+        mats[:, :3, :3] = poses[test_img_idx][:3, :3]
+        return mats.astype(np.float32)
+    from .datasets import poses_avg
+    avg = np.eye(4)
+    avg[:3, :4] = poses_avg(poses[:, :3, :4])[:3, :4]
+    return (avg[None] @ mats).astype(np.float32)
+
+
+def get_sphere_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: int, fps_render_video: int,
+                                      is_spherical_dataset: bool, estimated_intersection=None,
+                                      blender_scale_and_distance: Optional[Tuple[float, float]] = None,
+                                      seconds: int = 6) -> np.ndarray:
+    """src/ExecutionRun.py:389-413: one turn about y and one about x on the unit sphere.  Spherical datasets:
+    rotated so that the first pose has the test view's orientation and centred on the scene's point of interest;
+    Blender left-to-right scenes (``blender_scale_and_distance`` = (c2w scale, average camera z before
+    recentring)): radius scaled and pushed back along the view axis."""
+    poses = np.asarray(camera_poses, np.float64)
+    mats = get_sphere_matrices(int(fps_render_video * seconds)).astype(np.float64)
+    if is_spherical_dataset:
+        rot = get_rotation_matrix_from_source_to_dest_mats(mats[0, :3, :3], poses[test_img_idx][:3, :3])
+        mats = rot @ mats
+        mats[:, :3, 3] += np.asarray(estimated_intersection, np.float64)
+    elif blender_scale_and_distance is not None:
+        scale, distance = blender_scale_and_distance
+        mats[:, :3, 3] *= scale * distance
+        mats[:, 2, 3] += -scale * distance
+    return mats.astype(np.float32)
+
+
+def get_path_c2w_matrices_to_render(camera_poses: np.ndarray, img_indices_for_path_video: Sequence[int],
+                                    fps_render_video: int, seconds: int = 2) -> np.ndarray:
+    """src/ExecutionRun.py:424-437: the closed slerp tour, 2 s per leg."""
+    return get_path_c2w_matrices(camera_poses, img_indices_for_path_video, int(fps_render_video * seconds))
+
+
+# ---------------------------------------------------------------------------------------------
 # depth tone-mapping (grayscale histogram equalisation)
 # ---------------------------------------------------------------------------------------------
 def histogram_equalize_depth(depth: np.ndarray) -> np.ndarray:

@@ -91,3 +91,25 @@ def test_ray_slab_partition():
         per = -(-total // world)
         assert all(c <= per for _, c in slabs)
     assert N.ray_slab(65536, 3, 8) == (3 * 8192, 8192)            # whole rows when H % P == 0
+
+
+def test_m0_invariant_of_the_fused_kernels(tmp_path):
+    """The fused MLP kernels own M0 without a clobber (mlp_common.h::dma_piece*); the Makefile keeps their ISA and
+    fails the build when compiler-generated code touches M0.  Here: the checker flags a planted hit, and the ISA
+    of the current build (when this tree was built with `make`) is clean."""
+    import glob
+    import subprocess
+    import sys as _sys
+    tool = os.path.join(ROOT, "tools", "check_m0.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text(";;#ASMSTART\n\ts_mov_b32 m0, s4\n;;#ASMEND\n\tv_readlane_b32 s5, v1, m0\n")
+    good = tmp_path / "good.s"
+    good.write_text(";;#ASMSTART\n\ts_mov_b32 m0, s4\n;;#ASMEND\n\tv_add_f32 v0, v1, v2 ; m0 in a comment\n")
+    assert subprocess.run([_sys.executable, tool, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([_sys.executable, tool, str(good)], capture_output=True).returncode == 0
+    isa = sorted(glob.glob(os.path.join(ROOT, "build", "csrc", "mlp_*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if isa:
+        r = subprocess.run([_sys.executable, tool] + isa, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        for p in isa:                       # the asm is really in there: the check is not vacuous
+            assert "global_load_lds_dwordx4" in open(p).read()

@@ -35,7 +35,7 @@ def test_recorded_psnr(oracle, golden_ckpt, tag):
     fine = oracle.unpack_blob(golden_ckpt["blob_fine"])
     img = golden_ckpt["img_" + tag].astype(np.float32) / np.float32(255)
     out = oracle.render_image(coarse, fine, golden_ckpt["c2w_" + tag], float(golden_ckpt["fov"]), 50, 50,
-                              float(golden_ckpt["near"]), float(golden_ckpt["far"]), 64, 128, seed=1)
+                              float(golden_ckpt["near"]), float(golden_ckpt["far"]), 64, 128, seed=1, batch_size=32)
     assert abs(oracle.psnr(out[0], img) - float(golden_ckpt["recorded_psnr_" + tag])) <= 0.3
 
 

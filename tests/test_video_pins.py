@@ -1,0 +1,128 @@
+"""Per-pixel pins against the reference's OWN rendered output: the MJPG frames of the three camera tours the shipped
+run wrote with its epoch-95 checkpoint (Results/50px_alexander_71pics_sphere_nerf_save_dir_4/video_save/*.avi ->
+tests/golden/alexander50_video_frames.npz, made by tests/golden/make_video_fixtures.py; every 10th frame).
+
+What is pinned, against reference output rather than against this repository's own restatement:
+  * rows (a1)-(a13): rays, both samplers, encodings, both networks, compositing  -> RGB frames
+  * row (a14) + (f2): depth = sum_s w*z, grayscale histogram equalisation         -> depth frames
+  * row (f2): the three tour builders (src/ExecutionRun.py:358-437) and the dataset loader feeding them
+  * the fp16 single-pass mode: the reference produced these frames under `mixed_float16` (src/ExecutionRun.py:220-221)
+
+Limits of the pin, stated: the frames went through JPEG (MJPG) and uint8 rounding, and the reference draws fresh
+stratified jitter per frame (no seed), so the comparison is PSNR, not elementwise.  Frames of views *behind* the
+captured hemisphere (middle of the sphere tour) are dominated by that jitter: two renders of ours with different
+seeds agree there only to 24-30 dB.  The per-frame bar is therefore  min(34 dB, self-PSNR - 4.5 dB), where
+self-PSNR is measured between two seeds of the path under test; on the l_to_r and path tours it is 34 dB for
+every frame (measured >= 36.4 dB), and the tour means are pinned as well.
+"""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NET = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05, "n_pos_enc_dim_xyz": 5,
+       "n_pos_enc_view_dir": 4, "n_angles_for_model": 2, "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
+RGB_BAR, RGB_SELF_MARGIN = 34.0, 4.5          # dB
+DEPTH_BAR, DEPTH_SELF_MARGIN = 30.0, 4.0      # dB (histogram equalisation amplifies small depth differences)
+RGB_MEAN_BAR = {"l_to_r": 39.5, "sphere": 33.0, "path": 36.5}      # measured 40.9 / 34.0 / 37.7
+DEPTH_MEAN_BAR = {"l_to_r": 37.0, "sphere": 27.0, "path": 36.0}    # measured 38.4 / 28.0 / 37.0
+
+
+def psnr(a, b):
+    return float(-10 * np.log10(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return np.load(os.path.join(ROOT, "tests", "golden", "alexander50_video_frames.npz"))
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import nerf_and_dietnerf_amd as N
+    images, poses, fov, near, far, avg, scale = N.get_data_from_colmap(os.path.join(ROOT, "tests", "golden", "alexander50"))
+    return {"poses": poses, "fov": fov, "near": near, "far": far}
+
+
+def tours(frames, scene):
+    """The camera matrices the reference rendered, from the product's tour builders + the two fixture constants of
+    the reference's randomised scene analysis."""
+    import nerf_and_dietnerf_amd as N
+    fps, ti = int(frames["fps_render_video"]), int(frames["test_img_idx"])
+    sph = bool(frames["is_spherical_dataset"])
+    t = {"l_to_r": N.get_l_to_r_c2w_matrices_to_render(scene["poses"], ti, fps, sph),
+         "sphere": N.get_sphere_c2w_matrices_to_render(scene["poses"], ti, fps, sph, frames["estimated_intersection"]),
+         "path": N.get_path_c2w_matrices_to_render(scene["poses"], frames["img_indices_for_path_video"], fps)}
+    for name, m in t.items():
+        assert len(m) == int(frames[name + "_n_frames"])       # 300 / 720 / 1320 frames, as the reference wrote
+    return t
+
+
+def test_fixture_constants(frames, scene):
+    assert bool(frames["is_spherical_dataset"])
+    assert [int(frames[k + "_n_frames"]) for k in ("l_to_r", "sphere", "path")] == [300, 720, 1320]
+    # the point of interest lies in front of the average camera, inside the unit sphere the poses were scaled to
+    poi = frames["estimated_intersection"]
+    assert np.linalg.norm(poi) < 1.0 and poi[2] < 0
+    # the l_to_r tour of a spherical dataset passes through the test view's own pose (frame at x = 0)
+    t = tours(frames, scene)["l_to_r"]
+    mid = 0.5 * (t[149] + t[150])
+    np.testing.assert_allclose(mid, scene["poses"][int(frames["test_img_idx"])], atol=1e-6)
+
+
+# (tour, stored-frame slot) rendered by the CPU oracle: ~4 s of OpenBLAS per 50x50 frame (32-ray batches keep the
+# (rows, 256) activations in cache; the batch size changes nothing else: draws are keyed by the ray index)
+ORACLE_FRAMES = [("l_to_r", 0), ("l_to_r", 15), ("l_to_r", 29), ("path", 3), ("path", 40), ("path", 70),
+                 ("path", 110), ("sphere", 0), ("sphere", 55), ("sphere", 65)]
+
+
+@pytest.mark.parametrize("tour,slot", ORACLE_FRAMES)
+def test_oracle_matches_reference_frames(oracle, golden_ckpt, frames, scene, tour, slot):
+    """The CPU restatement against the reference's rendered frame: RGB >= 34 dB, equalised depth >= 30 dB.
+    (The chosen sphere frames are views of the captured side, where the jitter floor is above the bar.)"""
+    import nerf_and_dietnerf_amd.video as V
+    coarse, fine = oracle.unpack_blob(golden_ckpt["blob_coarse"]), oracle.unpack_blob(golden_ckpt["blob_fine"])
+    f = int(frames[tour + "_index"][slot])
+    c2w = tours(frames, scene)[tour][f]
+    out = oracle.render_image(coarse, fine, c2w, scene["fov"], 50, 50, scene["near"], scene["far"], 64, 128, seed=f,
+                              batch_size=32)
+    ref = frames[tour + "_rgb"][slot].astype(np.float32) / 255
+    p_rgb = psnr(np.clip(out[0], 0, 1), ref)
+    depth = V.histogram_equalize_depth(oracle.depth_map(out[1], out[5]).reshape(50, 50))
+    p_dep = psnr(depth, frames[tour + "_depth"][slot].astype(np.float32) / 255)
+    print(f"{tour} frame {f}: oracle vs reference frame rgb {p_rgb:.2f} dB, equalised depth {p_dep:.2f} dB")
+    assert p_rgb >= RGB_BAR, p_rgb
+    assert p_dep >= DEPTH_BAR, p_dep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+def test_hip_path_matches_reference_frames(golden_ckpt, frames, scene, precision):
+    """Every stored frame of the three tours through video.render_video on the device, in all three arithmetic
+    modes (the single-pass fp16 mode is the reference's production policy, under which it rendered these frames)."""
+    import nerf_and_dietnerf_amd as N
+    model = N.NeRF(NET, {"n_render_samples_coarse": 64, "n_render_samples_fine": 128}, scene["near"], scene["far"],
+                   device=0)
+    model.set_weights(golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
+    model.ctx.set_precision(precision)
+    for tour, mats in tours(frames, scene).items():
+        idx = frames[tour + "_index"]
+        ref = frames[tour + "_rgb"].astype(np.float32) / 255
+        refd = frames[tour + "_depth"].astype(np.float32) / 255
+        a, ad = N.render_video(model, mats[idx], scene["fov"], 50, 50, seed=0, equalize_depth=True)
+        b, bd = N.render_video(model, mats[idx], scene["fov"], 50, 50, seed=100000, equalize_depth=True)
+        a, b = np.clip(a, 0, 1), np.clip(b, 0, 1)
+        p = np.array([psnr(a[k], ref[k]) for k in range(len(idx))])
+        p_self = np.array([psnr(a[k], b[k]) for k in range(len(idx))])
+        d = np.array([psnr(ad[k], refd[k]) for k in range(len(idx))])
+        d_self = np.array([psnr(ad[k], bd[k]) for k in range(len(idx))])
+        print(f"{precision} {tour}: rgb min {p.min():.2f} mean {p.mean():.2f} (self min {p_self.min():.2f}); "
+              f"depth min {d.min():.2f} mean {d.mean():.2f} (self min {d_self.min():.2f})")
+        bar = np.minimum(RGB_BAR, p_self - RGB_SELF_MARGIN)
+        assert np.all(p >= bar), (tour, np.where(p < bar)[0], p[p < bar])
+        dbar = np.minimum(DEPTH_BAR, d_self - DEPTH_SELF_MARGIN)
+        assert np.all(d >= dbar), (tour, np.where(d < dbar)[0], d[d < dbar])
+        assert p.mean() >= RGB_MEAN_BAR[tour] and d.mean() >= DEPTH_MEAN_BAR[tour], (tour, p.mean(), d.mean())
+        if tour != "sphere":
+            assert p.min() >= RGB_BAR, (tour, p.min())     # no frame of these tours needs the noise-floor clause

@@ -12,7 +12,7 @@ def check(path):
             inside = True
         elif "#ASMEND" in line:
             inside = False
-        elif not inside and re.search(r"\bm0\b", line) and not line.lstrip().startswith((";", ".")):
+        elif not inside and re.search(r"\bm0\b", line.split(";")[0]) and not line.lstrip().startswith("."):
             bad.append((i, line.rstrip()))
     return bad
 
