@@ -8,10 +8,24 @@ libnerf_mi355 without editing any reference file.  TensorFlow is only touched th
 import numpy as np
 
 
-def attach(model, device=0, precision="fp32", to_tensor=None, context_factory=None, seed_source=None):
+def keras_leaky_relu_alpha(keras_model):
+    """alpha of the LeakyReLU the reference builds its Dense layers with
+    (``Dense(hidden, activation=LeakyReLU(leaky_relu_alpha))``, src/NeRF.py:264-265,309-310): the first layer whose
+    ``activation`` is a LeakyReLU layer object carries it as ``.alpha``.  Raises if no such layer exists."""
+    for layer in getattr(keras_model, "layers", ()):
+        act = getattr(layer, "activation", None)
+        if act is not None and hasattr(act, "alpha"):
+            return float(np.asarray(act.alpha))
+    raise ValueError("cannot determine leaky_relu_alpha from the Keras model (no Dense layer with a LeakyReLU "
+                     "activation object); pass attach(..., leaky_relu_alpha=net_config['leaky_relu_alpha'])")
+
+
+def attach(model, device=0, precision="fp32", to_tensor=None, context_factory=None, seed_source=None,
+           leaky_relu_alpha=None):
     """model: the reference's NeRF (attributes used: n_pos_enc_dim_xyz, n_pos_enc_view_dir,
     n_angles_for_model, near_boundary, far_boundary, n_render_samples_coarse/_fine, batch_size_render,
-    model_coarse / model_fine with Keras ``get_weights()``).  Returns the Context (call ``refresh()`` on the
+    model_coarse / model_fine with Keras ``get_weights()``; ``leaky_relu_alpha`` is read from the coarse Keras model's
+    first LeakyReLU activation unless given).  Returns the Context (call ``refresh()`` on the
     returned object's ``refresh_weights`` after training steps)."""
     if to_tensor is None:
         import tensorflow as tf
@@ -22,8 +36,10 @@ def attach(model, device=0, precision="fp32", to_tensor=None, context_factory=No
     if seed_source is None:
         rng = np.random.default_rng()
         seed_source = lambda: int(rng.integers(0, 1 << 62))   # noqa: E731  fresh jitter per call, like tf.random
+    if leaky_relu_alpha is None:          # the reference's NeRF object does not keep its net_config: ask the Keras model
+        leaky_relu_alpha = keras_leaky_relu_alpha(model.model_coarse)
     ctx = context_factory(n_pos_enc_xyz=model.n_pos_enc_dim_xyz, n_pos_enc_dir=model.n_pos_enc_view_dir,
-                          n_angles=model.n_angles_for_model, leaky_relu_alpha=0.05,
+                          n_angles=model.n_angles_for_model, leaky_relu_alpha=float(leaky_relu_alpha),
                           near=model.near_boundary, far=model.far_boundary, precision=precision, device=device)
 
     def refresh_weights():

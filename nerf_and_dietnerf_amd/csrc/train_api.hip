@@ -362,6 +362,10 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     const bool fine = Sf > 0 && t->net[1].present;
     if (fine && Sc < 2) return fail("hierarchical sampling needs at least 2 coarse samples (got %d)", Sc);
     if (fine && Sf > 256) return fail("training supports at most 256 fine samples per ray (got %d)", Sf);
+    // same budget as the render path's sampler (nerf_api.hip): the backward sampler was validated up to 64 KiB of LDS
+    if (fine && (sample_pdf_lds_bytes(Sc, Sf) > 64 * 1024 || sample_pdf_bwd_lds_bytes(Sc, Sf) > 64 * 1024))
+        return fail("Sc=%d Sf=%d exceeds the sampler's LDS budget (forward %zu B, backward %zu B, limit 65536 B)", Sc, Sf,
+                    sample_pdf_lds_bytes(Sc, Sf), sample_pdf_bwd_lds_bytes(Sc, Sf));
     const size_t f = sizeof(float);
     const float *o, *d, *tg, *uc, *uf;
     if (int r = stage_in(c, t->o, rays_o, N * 4 * f, mem, &o)) return r;

@@ -35,8 +35,10 @@ class RayDataset:
     """All training rays in HBM; iterating yields shuffled batches (rays_orig, rays_dirs, real_rgb) of
     ``batch_size`` rays (the last one of an epoch may be smaller, as tf.data's ``batch`` leaves it).
 
-    ``rank``/``world`` give every data-parallel rank a disjoint 1/world share of each (identically shuffled)
-    batch, so that the averaged gradient is the gradient of the whole batch."""
+    ``rank``/``world`` give every data-parallel rank a disjoint share of each (identically shuffled) batch.  All
+    shares have the SAME number of rays -- floor(len(batch) / world); the up to world-1 left-over rays of a batch
+    are dropped, and a batch shorter than ``world`` is skipped by every rank -- so the plain mean of the per-rank
+    gradients is the gradient of the rays used, and no rank ever enters the all-reduce without rays."""
 
     def __init__(self, orig, dirs, rgb, batch_size: int, seed: int = 0, rank: int = 0, world: int = 1):
         assert batch_size > 0
@@ -59,7 +61,9 @@ class RayDataset:
         for b in range(len(self)):
             idx = perm[b * self.batch_size:(b + 1) * self.batch_size]
             if self.world > 1:
-                per = -(-idx.numel() // self.world)
+                per = idx.numel() // self.world
+                if per == 0:
+                    continue                     # fewer rays than ranks: the same decision on every rank
                 idx = idx[self.rank * per:(self.rank + 1) * per]
             yield self.orig[idx], self.dirs[idx], self.rgb[idx]
 

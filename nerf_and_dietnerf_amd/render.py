@@ -497,8 +497,8 @@ class NeRF:
         from .sharding import allreduce_mean
         metrics, gc, gf = self.ctx.train_gradients(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f,
                                                    u_coarse, u_fine, seed)
-        gc = allreduce_mean(gc, group)
-        gf = allreduce_mean(gf, group) if gf is not None else None
+        gc = allreduce_mean(gc, group, self.ctx.cfg.device)
+        gf = allreduce_mean(gf, group, self.ctx.cfg.device) if gf is not None else None
         self.ctx.train_apply(gc, gf)
         return metrics
 

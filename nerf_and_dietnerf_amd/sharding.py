@@ -71,17 +71,34 @@ def dist_world(group=None) -> int:
     return dist.get_world_size(group)
 
 
-def allreduce_mean(blob, group=None):
-    """Mean of a flat fp32 blob over the ranks of ``group`` (numpy in -> numpy out, CUDA tensor in place)."""
+def collective_device(tensor_is_cuda: bool, backend: str, cuda_device=None):
+    """Where a tensor has to live for a collective of ``backend``: "cpu", ("cuda", index) or None (= where it is).
+    nccl (RCCL) moves device memory only; gloo (this image's build) host memory only."""
+    if backend == "nccl":
+        return None if tensor_is_cuda else ("cuda", cuda_device)
+    if backend == "gloo":
+        return "cpu" if tensor_is_cuda else None
+    return None
+
+
+def allreduce_mean(blob, group=None, cuda_device=None):
+    """Mean of a flat fp32 blob over the ranks of ``group``: numpy in -> numpy out, torch tensor in -> tensor on the
+    same device out.  The data is staged to wherever the group's backend can reduce it (a host array under
+    nccl/RCCL goes through this rank's GPU, ``cuda_device`` or torch's current one; a CUDA tensor under gloo
+    through the host)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     is_np = isinstance(blob, np.ndarray)
     t = torch.from_numpy(blob) if is_np else blob
-    dev = t.device
-    if t.is_cuda and dist.get_backend(group) == "gloo":
-        t = t.cpu()                      # one-GPU rehearsal: gloo has no CUDA all-reduce
+    home = t.device
+    where = collective_device(t.is_cuda, dist.get_backend(group), cuda_device)
+    if where == "cpu":
+        t = t.cpu()
+    elif where is not None:
+        t = t.to(torch.device("cuda", torch.cuda.current_device() if where[1] is None else where[1]))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t /= world
-    return t.numpy() if is_np else t.to(dev)
+    t = t.to(home)
+    return t.numpy() if is_np else t

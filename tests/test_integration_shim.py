@@ -11,9 +11,20 @@ shim = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(shim)
 
 
+class _LeakyReLU:                      # stand-in for keras.layers.LeakyReLU (attribute `alpha`)
+    def __init__(self, alpha):
+        self.alpha = np.float32(alpha)
+
+
+class _Dense:
+    def __init__(self, activation):
+        self.activation = activation
+
+
 class _Keras:
-    def __init__(self, tag):
+    def __init__(self, tag, alpha=0.05):
         self.tag = tag
+        self.layers = [object(), _Dense(_LeakyReLU(alpha)), _Dense(None)] if alpha is not None else [object()]
 
     def get_weights(self):
         return [np.full((2, 2), self.tag, np.float32)]
@@ -75,3 +86,17 @@ def test_attach_coarse_only():
     assert 1 not in ctx.loaded
     out = model.render(np.zeros((2, 4)), np.zeros((2, 4)))
     assert out[5].shape == (2, 64) and ctx.calls[-1] == ("render", (2, 4), 64, 0, 1)
+
+
+def test_alpha_is_read_from_the_keras_model():
+    import pytest
+    m = _RefModel()
+    m.model_coarse = _Keras(1.0, alpha=0.2)
+    ctx = shim.attach(m, to_tensor=lambda x: x, context_factory=_FakeCtx, seed_source=lambda: 1)
+    assert abs(ctx.kw["leaky_relu_alpha"] - 0.2) < 1e-7
+    m2 = _RefModel()
+    m2.model_coarse = _Keras(1.0, alpha=None)            # no LeakyReLU to be found: refuse to guess
+    with pytest.raises(ValueError):
+        shim.attach(m2, to_tensor=lambda x: x, context_factory=_FakeCtx, seed_source=lambda: 1)
+    ctx = shim.attach(m2, to_tensor=lambda x: x, context_factory=_FakeCtx, seed_source=lambda: 1, leaky_relu_alpha=0.1)
+    assert ctx.kw["leaky_relu_alpha"] == 0.1

@@ -96,7 +96,9 @@ class _FakeCtx:
     loaded = [True, True]
 
     def __init__(self):
+        import types
         self.applied = None
+        self.cfg = types.SimpleNamespace(device=0)
 
     def train_begin(self, *a, **k):
         pass

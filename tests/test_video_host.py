@@ -161,3 +161,37 @@ def test_ray_dataset_batches_and_rank_shares():
     for (a, _, _), (b, _, _), (f, _, _) in zip(r0, r1, full):
         both = torch.cat([a[:, 0], b[:, 0]])
         assert both.numel() == f.shape[0] and torch.equal(torch.sort(both).values, torch.sort(f[:, 0]).values)
+
+
+def test_ray_dataset_shares_are_equal_when_the_batch_does_not_divide():
+    """Data-parallel shares of a short last batch: every rank gets floor(L / world) rays (the plain mean of the rank
+    gradients is then the gradient of the rays used) and a batch with fewer rays than ranks is skipped by all ranks --
+    no rank may reach the gradient all-reduce with an empty shard (nerf_train_gradients rejects N = 0)."""
+    import torch
+    from nerf_and_dietnerf_amd.dataset import RayDataset
+    world = 8
+    for n, batch in ((256 + 49, 256), (256 + 5, 256), (1000, 256)):        # last batch: 49 / 5 (< world) / 232 rays
+        ids = torch.arange(n, dtype=torch.float32)
+        orig = ids[:, None].expand(n, 4).contiguous()
+        per_rank = [[o[:, 0] for o, _, _ in RayDataset(orig, orig, orig[:, :3].contiguous(), batch, seed=3, rank=r,
+                                                       world=world)] for r in range(world)]
+        full = [o[:, 0] for o, _, _ in RayDataset(orig, orig, orig[:, :3].contiguous(), batch, seed=3)]
+        n_batches = {len(p) for p in per_rank}
+        assert len(n_batches) == 1                                        # all ranks take the same number of steps
+        kept = [f for f in full if f.numel() >= world]
+        assert n_batches.pop() == len(kept)
+        for b, f in enumerate(kept):
+            shares = [p[b] for p in per_rank]
+            assert {s.numel() for s in shares} == {f.numel() // world}   # equal, non-empty
+            both = torch.cat(shares)
+            assert both.unique().numel() == both.numel()                  # disjoint
+            assert set(both.tolist()) <= set(f.tolist())
+
+
+def test_collective_staging_rule():
+    """Where allreduce_mean stages its data: RCCL (nccl) reduces device memory only, gloo host memory only."""
+    from nerf_and_dietnerf_amd.sharding import collective_device
+    assert collective_device(False, "nccl", 3) == ("cuda", 3)      # host gradient blob under nccl -> this rank's GPU
+    assert collective_device(True, "nccl", 3) is None
+    assert collective_device(True, "gloo") == "cpu"                # one-GPU rehearsal
+    assert collective_device(False, "gloo") is None
