@@ -85,6 +85,8 @@ def main():
                          "(fp32-class accuracy, tests/test_gpu_parity.py); fp32 = exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline + fp32 + fp16 modes only: skip the sustained run, the shipped-weights run and configs 4/5")
     ap.add_argument("--c-gather", action="store_true",
                     help="N>1: assemble the frame with the library's own ncclAllGather (nerf_render_image_sharded) "
                          "instead of torch.distributed.all_gather_into_tensor")
@@ -149,17 +151,93 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                        # torch's current stream == the library's stream (use_torch_stream)
+        return e
+
+    def step_marked(seed, marks):
+        """One step with stream events around its two halves: render of this rank's slab, then the gather."""
+        e0 = ev()
+        if c_gather:
+            rgb = model.ctx.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=seed, device_out=True)
+            e1 = e2 = ev()                # render + ncclAllGather are one library call: not separable here
+        else:
+            rgb = model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=seed, ray_begin=begin,
+                                     ray_count=count, device_out=True, rgb_only=True)[0]
+            e1 = ev()
+            if world > 1:
+                rgb = N.gather_slabs(rgb, total)
+            e2 = ev()
+        marks.append((e0, e1, e2))
+        return rgb
+
+    if world > 1 and backend == "nccl":
+        # the two assemblies of the frame (torch collective vs the library's own ncclAllGather) must agree bit for bit
+        if not c_gather:
+            model.ctx.comm_init_from_torch()
+        a_img = model.ctx.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=12345, device_out=True)
+        b_img = N.gather_slabs(model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=12345, ray_begin=begin,
+                                                  ray_count=count, device_out=True, rgb_only=True)[0], total)
+        if not torch.equal(a_img.reshape(-1, 3), b_img.reshape(-1, 3)):
+            raise SystemExit(f"rank {rank}: nerf_render_image_sharded (RCCL inside the library) and the torch all-gather "
+                             f"assemble different frames (max diff {float((a_img.reshape(-1, 3) - b_img).abs().max())})")
+        gather_check = "c-level ncclAllGather image == torch all_gather image, bit for bit (checked in warm-up)"
+    else:
+        gather_check = None
+
     for i in range(args.warmup):
         img = step(i)
     sync()
+    marks = []
     model.ctx.enable_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        img = step(args.warmup + i)
+        img = step_marked(args.warmup + i, marks)
     sync()
     elapsed = time.perf_counter() - t0
     mlp_ms, n_launch, n_rows = model.ctx.read_timing()
     model.ctx.enable_timing(False)
+    # per-step GPU times from the stream events (no host synchronisation inside the timed region)
+    step_ms = [marks[i][0].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)]
+    render_ms = [m[0].elapsed_time(m[1]) for m in marks]
+    gather_ms = [m[1].elapsed_time(m[2]) for m in marks]
+    gap_ms = [marks[i][2].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)]   # stream idle between steps
+    med = lambda v: float(np.median(v)) if len(v) else None       # noqa: E731
+    attribution = {"rank": rank, "slab_rays": int(count), "render_ms_median": med(render_ms),
+                   "mlp_kernel_ms_per_step": mlp_ms / max(args.steps, 1), "gather_ms_median": med(gather_ms),
+                   "host_gap_ms_median": med(gap_ms), "step_ms_median": med(step_ms)}
+    per_rank = [attribution]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, attribution)
+        per_rank = box
+
+    # K frames in flight between gathers: separates launch latency at small slabs from gather bandwidth (N>1 only)
+    in_flight = None
+    if world > 1 and not c_gather:
+        K = 8
+        def step_k(seed0):
+            parts = [model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=seed0 + k, ray_begin=begin,
+                                        ray_count=count, device_out=True, rgb_only=True)[0] for k in range(K)]
+            slab = torch.stack(parts, dim=1)                       # (rays of the slab, K, 3): one gather for K frames
+            return N.gather_slabs(slab, total)
+        step_k(0)
+        sync()
+        tk = time.perf_counter()
+        reps = max(1, args.steps // 2)
+        for i in range(reps):
+            out_k = step_k(1000 + i * K)
+        sync()
+        ek = time.perf_counter() - tk
+        tt = torch.tensor([ek], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ek = float(tt.item())
+        assert tuple(out_k.shape) == (total, K, 3)
+        in_flight = {"frames_per_gather": K, "value": total * K * reps / ek, "unit": "rays/s",
+                     "ms_per_frame": ek / (K * reps) * 1e3,
+                     "note": "K frames of this rank's slab rendered back to back, ONE all-gather of (rays, K, 3); "
+                             "extra figure, not the headline"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,46 +246,76 @@ def main():
     if args.rehearse_world > 1:
         args.no_cpu_baseline = True
 
-    # the exact-fp32 mode of the same step, timed briefly beside the headline mode (N=1 only)
-    other = None
-    if world == 1 and args.precision == "f16x3" and args.rehearse_world <= 1:
-        model.ctx.set_precision("fp32")
-        step(0)
-        sync()
-        model.ctx.enable_timing(True)
-        t1 = time.perf_counter()
-        for i in range(3):
-            step(i)
-        sync()
-        e32 = time.perf_counter() - t1
-        ms32, nl32, rows32 = model.ctx.read_timing()
-        model.ctx.enable_timing(False)
-        model.ctx.set_precision("f16x3")
-        a32 = rows32 * FLOPS_PER_ROW / (ms32 * 1e-3) / 1e12
-        other = {"dtype": "f32", "value": total * 3 / e32, "unit": "rays/s", "steps": 3,
-                 "roofline": {"bound": "mfma", "kernel": "mlp_fp32_kernel", "achieved": a32, "peak": PEAK_TFLOPS["f32"],
-                              "unit": "TFLOP/s", "frac": a32 / PEAK_TFLOPS["f32"]}}
+    def roof(kernel, rows, ms, dtype_key):
+        a = rows * FLOPS_PER_ROW / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_TFLOPS[dtype_key], "unit": "TFLOP/s",
+                "frac": a / PEAK_TFLOPS[dtype_key], "rows": int(rows), "flops_per_row": FLOPS_PER_ROW}
 
-    # the single-pass fp16 mode (the reference's production mixed_float16 numerics class; BASELINE configs[4] "fp16 MLP")
-    fp16_mode = None
+    KERNEL = {"fp32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel", "f16": "mlp_f16_kernel"}
+    DKEY = {"fp32": "f32", "f16x3": "f16x3", "f16": "f16"}
+
+    def side_run(mdl, precision, k, h, w, sc, sf, pose, fov, batch=1 << 18, min_seconds=0.0):
+        """k frames (or at least min_seconds of them) of (h, w, sc+sf) in `precision` on `mdl`: rays/s, median step,
+        roofline of the fused kernel from the library's own HIP events."""
+        mdl.ctx.set_precision(precision)
+        f = lambda sd: mdl.render_image(pose, fov, h, w, batch_size_input=batch, n_render_samples_c=sc,   # noqa: E731
+                                        n_render_samples_f=sf, seed=sd, device_out=True, rgb_only=True)[0]
+        f(0)
+        sync()
+        mdl.ctx.enable_timing(True)
+        evs = [ev()]
+        t = time.perf_counter()
+        n = 0
+        while n < k or (time.perf_counter() - t) < min_seconds:
+            f(n + 1)
+            evs.append(ev())
+            n += 1
+            if min_seconds > 0 and n % 16 == 0:
+                torch.cuda.synchronize()          # bound the queue while filling a wall-clock budget
+        sync()
+        e = time.perf_counter() - t
+        ms, nl, rows = mdl.ctx.read_timing()
+        mdl.ctx.enable_timing(False)
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+        rows_per_ray = sc + (sc + sf if sf else 0)
+        return {"value": h * w * n / e, "unit": "rays/s", "steps": n, "seconds": e, "ms_per_step": e / n * 1e3,
+                "ms_per_step_median": float(np.median(per)), "mlp_rows_per_ray": rows_per_ray,
+                "flops_per_ray": rows_per_ray * FLOPS_PER_ROW,
+                "roofline": dict(roof(KERNEL[precision], rows, ms, DKEY[precision]), launches=int(nl),
+                                 avg_launch_ms=ms / max(nl, 1))}
+
+    other = fp16_mode = sustained = shipped = cfg4 = cfg5 = None
     if world == 1 and args.precision == "f16x3" and args.rehearse_world <= 1:
-        model.ctx.set_precision("f16")
-        step(0)
-        sync()
-        model.ctx.enable_timing(True)
-        t3 = time.perf_counter()
-        for i in range(5):
-            step(i)
-        sync()
-        e16 = time.perf_counter() - t3
-        ms16, nl16, rows16 = model.ctx.read_timing()
-        model.ctx.enable_timing(False)
+        # the exact-fp32 mode and the single-pass fp16 mode of the same step, beside the headline mode
+        other = dict(side_run(model, "fp32", 3, H, W, SC, SF, c2w, FOV), dtype="f32")
+        other["roofline"]["frac_vs_fp32_matrix_peak"] = other["roofline"]["frac"]
+        fp16_mode = dict(side_run(model, "f16", 5, H, W, SC, SF, c2w, FOV),
+                         dtype="f16 (single pass, fp16 activations between layers: mixed_float16-class, not the fp32 parity mode)")
+        if not args.quick:
+            # >= 10 s of back-to-back frames in the headline mode: the sustained (thermal / DVFS steady-state) rate
+            sustained = dict(side_run(model, "f16x3", 1, H, W, SC, SF, c2w, FOV, min_seconds=10.0),
+                             note="headline mode, same frame, >= 10 s of wall clock")
+            # SURVEY 8d input set (A): the reference's shipped epoch-95 weights (operand statistics of a trained net)
+            ck = os.path.join(ROOT, "tests", "golden", "alexander50_epoch095.npz")
+            if os.path.exists(ck):
+                g = np.load(ck)
+                m_a = N.NeRF(net_cfg, {"n_render_samples_coarse": SC, "n_render_samples_fine": SF}, float(g["near"]),
+                             float(g["far"]), device=dev_index, precision="f16x3")
+                m_a.set_weights(g["blob_coarse"], g["blob_fine"])
+                m_a.ctx.use_torch_stream()
+                shipped = dict(side_run(m_a, "f16x3", args.steps, H, W, SC, SF, g["c2w_test"], float(g["fov"])),
+                               weights="reference's shipped Alexander epoch-95 checkpoint (data fixture), its test-view "
+                                       "pose / bounds / fov at 256x256; headline mode")
+                shipped["fp16_single_pass"] = side_run(m_a, "f16", 5, H, W, SC, SF, g["c2w_test"], float(g["fov"]))
+                m_a.ctx.close()
+            # BASELINE configs[3]: DietNeRF consistency-render shape (150x150, 55+55, batches of 2048 rays)
+            cfg4 = dict(side_run(model, "f16x3", 20, 150, 150, 55, 55, c2w, FOV, batch=2048),
+                        workload="150x150, 55 coarse + 55 fine, 2048-ray batches (src/DietNeRF.py:215-218), headline mode")
+            # BASELINE configs[4]: 800x800, 64 coarse + 256 fine, fp16 MLP
+            cfg5 = dict(side_run(model, "f16", 3, 800, 800, 64, 256, c2w, FOV),
+                        workload="800x800, 64 coarse + 256 fine (fine pass 320 samples), single-pass fp16 MLP mode")
+            cfg5["f16x3_mode"] = side_run(model, "f16x3", 2, 800, 800, 64, 256, c2w, FOV)
         model.ctx.set_precision("f16x3")
-        a16 = rows16 * FLOPS_PER_ROW / (ms16 * 1e-3) / 1e12
-        fp16_mode = {"dtype": "f16 (single pass, fp16 activations between layers: mixed_float16-class, not the fp32 parity mode)",
-                     "value": total * 5 / e16, "unit": "rays/s", "steps": 5,
-                     "roofline": {"bound": "mfma", "kernel": "mlp_f16_kernel", "achieved": a16, "peak": PEAK_TFLOPS["f16"],
-                                  "unit": "TFLOP/s", "frac": a16 / PEAK_TFLOPS["f16"]}}
 
     # the training step (SURVEY.md 8f rank 3) on the reference's batch, timed briefly beside the headline (N=1 only)
     train = None
@@ -247,7 +355,10 @@ def main():
             value = count * args.rehearse_world * args.steps / elapsed
         dtype = {"fp32": "f32", "f16x3": "f16x3", "f16": "f16"}[args.precision]
         ach = (n_rows * FLOPS_PER_ROW) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-        traffic = None      # PMC figure of the N=1 launches (profiles/pmc_traffic.json); smaller slabs at N>1: not measured
+        # roofline.traffic: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction),
+        # collected OFFLINE for the N=1 launches and kept in profiles/pmc_traffic.json -- PMC counters cannot be read
+        # from inside this process; smaller slabs at N>1: not measured
+        traffic = None
         try:
             if world > 1:
                 raise LookupError
@@ -258,7 +369,8 @@ def main():
         out = {
             "metric": "rays/sec (coarse+fine) at 256x256, 64 coarse + 128 fine samples",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": med(step_ms),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                       "f16": "f16 (single pass, f32 accumulate, fp16 activations: mixed_float16-class results, NOT the fp32 parity mode)"}[dtype],
@@ -271,13 +383,21 @@ def main():
                          "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[dtype], "frac_vs_fp32_matrix_peak": ach / PEAK_TFLOPS["f32"],
                          "mfma_passes_per_product": 3 if dtype == "f16x3" else 1, "traffic": traffic,
+                         "traffic_source": "offline rocprofv3 PMC (profiles/pmc_traffic.json), bytes per average launch",
                          "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),
                          "flops_per_row": FLOPS_PER_ROW, "rows": int(n_rows)},
         }
-        if other is not None:
-            out["fp32_exact_mode"] = other
-        if fp16_mode is not None:
-            out["fp16_single_pass_mode"] = fp16_mode
+        for key, val in (("fp32_exact_mode", other), ("fp16_single_pass_mode", fp16_mode), ("sustained", sustained),
+                         ("shipped_checkpoint_weights", shipped), ("config4_dietnerf_shape", cfg4),
+                         ("config5_800x800_fp16", cfg5), ("frames_in_flight", in_flight)):
+            if val is not None:
+                out[key] = val
+        if world > 1:
+            out["per_rank"] = per_rank
+            out["gather"] = {"kind": "library ncclAllGather (--c-gather)" if c_gather else "torch all_gather_into_tensor",
+                             "bytes_per_rank": int(-(-total // world) * 12), "check": gather_check}
+        else:
+            out["per_rank"] = per_rank
         if train is not None:
             out["training"] = train
         if world == 1 and not args.no_cpu_baseline:

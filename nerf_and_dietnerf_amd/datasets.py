@@ -104,21 +104,24 @@ def get_data_from_colmap(dataset_location: str):
     return images.astype(np.float32), poses.astype(np.float32), field_of_view, near, far, average_c2w, scale
 
 
-def get_data_from_blender(dataset_location: str, near_boundary: float, far_boundary: float):
+def get_data_from_blender(dataset_location: str, near_boundary: float, far_boundary: float, load_images: bool = True):
+    """``load_images=False`` (not in the reference) returns poses and camera constants only, ``images`` = None --
+    for render-only callers that have the ``cam_data.json`` of a rig but not its pictures."""
     dataset_location = str(dataset_location)
     with open(os.path.join(dataset_location, CAM_DATA_JSON_FILE_NAME), "r") as f:
         meta = json.load(f)
     mats, images = [], []
     for frame in meta["frames"]:
         mats.append(frame["transformation_matrix"])
-        images.append(imread(os.path.join(dataset_location, frame["filename"])))
-    images = np.asarray(images, dtype=np.float32)
+        if load_images:
+            images.append(imread(os.path.join(dataset_location, frame["filename"])))
+    images = np.asarray(images, dtype=np.float32) if load_images else None
     cams = np.asarray(mats, dtype=np.float64)
     cams, average_c2w = recenter_poses(cams)
     bounds = np.array([near_boundary, far_boundary], dtype=np.float64)
     cams, bounds, scale = spherify_poses(cams, bounds)
-    return (images / 255.0, cams.astype(np.float32), float(meta["field_of_view"]), float(bounds[0]), float(bounds[1]),
-            average_c2w, scale)
+    return (None if images is None else images / 255.0, cams.astype(np.float32), float(meta["field_of_view"]),
+            float(bounds[0]), float(bounds[1]), average_c2w, scale)
 
 
 def get_train_images_indices(n_images: int, idx_test: int, pics_indices_to_use_in_dataset=None) -> List[int]:
