@@ -1,0 +1,509 @@
+// mlp_bwd_f16x3.hip -- the training path's fused data-gradient chain: one kernel walks a 128-row tile of samples
+// backwards through the Dense stack (layer 8 .. layer 1 [, the encoding rows of layers 4 and 0]) with the gradient
+// kept on the lane from layer to layer, exactly as mlp_f16x3.hip walks it forwards.
+//
+// Reference: the backward of NeRF.train_step's tape (src/NeRF.py:136-167) through the Keras model of
+// src/NeRF.py:316-339 -- for every sample row
+//     G9  = (W9 . d_rgb) * LeakyReLU'(h9)                                       (rgb head, VALU)
+//     D7  = (W8[hidden rows] . G9 + W10[hidden rows] * d_sigma) * LeakyReLU'(h8)
+//     D_l-1 = (W_l . D_l) * LeakyReLU'(h_l)          l = 7 .. 1   (layer 4: its 256 hidden rows)
+//     dXa = W4[xyz rows] . D4,  dXb = W0 . D0        (gradient w.r.t. the xyz encoding; only for the sampler term)
+// where D_l is the gradient w.r.t. the pre-activation of layer l.  It replaces the layer-by-layer gemm_abt_h launches
+// (train_kernels.hip) whose every operand made a round trip through HBM.
+//
+// Same skeleton as the forward kernel: one wave per SIMD, 32 samples per wave with the sample on the lane,
+// D^T = W . D_next^T on v_mfma_f32_32x32x16_f16 in three passes over hi/lo split operands (fp32-class results), the
+// accumulator -- after the LeakyReLU' mask -- re-packed as the next layer's B operand, weights (here the
+// NON-transposed kernels, one 32-row tile of input features per accumulator) streamed L2 -> LDS ring by LDS-DMA.
+// What is new:
+//   * LeakyReLU' comes from a 1-bit-per-activation record written by the stash forward (mlp_f16x3.hip): the lane loads
+//     one 16-byte word per layer whose bit 16 ut + r is the mask of its accumulator register r of tile ut;
+//   * gradients are tiny and grow or shrink from layer to layer, fp16 has 5 exponent bits: every SAMPLE (= lane) carries
+//     its own power-of-two scale, renewed per layer from the largest entry of that sample's operand, so that the packed
+//     operand peaks between 2^5 and 2^12 for every row independently (the layer-wise GEMM could only scale whole
+//     buffers); scaling a column of B scales that column of the product, so the epilogue undoes it exactly;
+//   * every D_l is also written in fp32 (true scale) for the weight-gradient GEMMs, with max|D_l| for their scaling.
+#include "mlp_f16_frag.h"
+
+#include <string.h>
+
+namespace nerf {
+
+// ---- stream geometry: bodies in execution order, each padded to whole 32-quad chunks ----
+constexpr int kBStepsHead = 9;                 // 128 features of G9 (8 k-steps) + 1 k-step carrying d_sigma
+constexpr int kBChunksHead = (8 * 2 * kBStepsHead + kHCQ - 1) / kHCQ;     // 144 quads -> 5
+constexpr int kBChunksHid = (8 * 2 * 16) / kHCQ;                          // 8
+constexpr int kBChunksHidX = ((8 + 2) * 2 * 16) / kHCQ;                   // 10: layer 4 with its two encoding tiles
+constexpr int kBChunksXyz = (2 * 2 * 16) / kHCQ;                          // 2: layer 0's encoding rows
+constexpr int kBStreamChunks = kBChunksHead + 7 * kBChunksHid;                                  // 61
+constexpr int kBStreamChunksDx = kBChunksHead + 6 * kBChunksHid + kBChunksHidX + kBChunksXyz;   // 65
+static_assert((size_t)kBStreamChunksDx * kHChunkBytes == kBwdStreamBytes, "backward stream size mismatch");
+
+constexpr int kBConstWrgb = 2208;     // the forward kernel's constant block is reused: [3][128] rgb head weights
+constexpr int kBConstFloats = 2608;
+constexpr int kBLdsGmax = kLdsConst + kBConstFloats * 4;   // 9 x uint32: max|D| bits per gradient buffer, then spare
+static_assert(kBConstFloats + 16 <= kConstFloats, "gmax slots must fit the shared LDS carve");
+
+enum { BW_HEAD = 0, BW_HID = 1, BW_XYZ = 2 };
+
+__device__ __forceinline__ uint32_t* lds_gmax() {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    return reinterpret_cast<uint32_t*>(smem + kBLdsGmax);
+}
+
+struct BwdLane {          // per-lane (= per-sample) scale state
+    float inv_sig;        // 1 / (scale of the current body's input operand)
+    float rho;            // power of two applied to the current body's outputs when they are packed
+    float inv_prev, rho_prev;   // the same two numbers of the previous body (for its pending last tile)
+    float mrun;           // running max |packed value| of the operand being produced
+};
+
+__device__ __forceinline__ float pow2_to_peak(float m) {
+    // power of two r with m * r in (2^5, 2^6]  (1 for m == 0): exponent arithmetic on the bits
+    const uint32_t b = __float_as_uint(m);
+    int e = 259 - (int)(b >> 23);
+    e = e < 1 ? 1 : e > 254 ? 254 : e;
+    return b == 0u ? 1.0f : __uint_as_float((uint32_t)e << 23);
+}
+__device__ __forceinline__ float pow2_inverse(float r) { return __uint_as_float(0x7F000000u - __float_as_uint(r)); }
+__device__ __forceinline__ float max_with_other_half(float v) {   // max over the two lanes (j, 0) and (j, 1) of a sample
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+// 1.0 or alpha by bit `BIT` of w: sign-extended bit -> all-ones / zero -> bitfield insert (3 plain VALU ops with the mul)
+template <int BIT>
+__device__ __forceinline__ float mask_factor(uint32_t w, float alpha) {
+    const int m = ((int)(w << (31 - BIT))) >> 31;
+    return __uint_as_float(((uint32_t)m & 0x3F800000u) | (~(uint32_t)m & __float_as_uint(alpha)));
+}
+
+// One transposed layer.  Tiles 0..NX-1 produce rows of the encoding gradient (true scale, no mask, not re-packed), the
+// NH = 8 (0 for BW_XYZ) tiles after them the masked gradient of the 256 hidden features.  As in the forward kernel the
+// epilogue of a tile is dealt out over the NEXT tile's k-steps and the last hidden tile is finished by the next body
+// (PEND).  copy_tail: the previous body staged its outputs in nh/nl (an in-place BW_HID body), so fragments 12..13
+// still have to move to xh/xl; after BW_HEAD (which writes xh/xl directly) they must not.
+template <int KIND, int NX, bool PEND>
+__device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, BwdLane& L, bool copy_tail,
+                                         float* d_prev, float* d_cur, float* dx_cur, const frag4& mk_prev,
+                                         const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[4], frag4 (&xh)[16],
+                                         frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14]) {
+    constexpr int NH = KIND == BW_XYZ ? 0 : 8;
+    constexpr int NU = NX + NH;
+    constexpr int NSTEP = KIND == BW_HEAD ? kBStepsHead : 16;
+    constexpr int QPU = 2 * NSTEP;
+    constexpr int NQ = NU * QPU;
+    constexpr int kPf = 4;
+    f32x4 pf[kPf];
+    const int ck0 = p.ck;
+    uint32_t rdbase[2];
+    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kHRing - 1)) * kHChunkBytes;
+    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kHRing - 1)) * kHChunkBytes;
+    auto issue_read = [&](auto qc) {
+        constexpr int Qa = decltype(qc)::value;
+        lds_read_frag_asm<(Qa % kHCQ) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kHCQ) & 1]);
+    };
+    static_for<0, kPf>([&](auto ic) {
+        if constexpr (decltype(ic)::value < NQ) issue_read(ic);
+    });
+
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;      // true-scale values waiting for the 4th of their float4
+    float pc = 0.f;                          // packed-scale value waiting for its pair
+    (void)q0; (void)q1; (void)q2; (void)pc;
+    // true-scale store of registers r-3..r (r & 3 == 3) of a tile whose 32 rows start at column c0 of `base`
+    auto store4 = [&](float* base, int c0, int r, float v) {
+        f32x4 o;
+        o[0] = q0; o[1] = q1; o[2] = q2; o[3] = v;
+        *reinterpret_cast<f32x4*>(base + c0 + 8 * (r >> 2)) = o;
+    };
+    // register r of hidden tile ht: mask, write the true value, scale + split + pack into the next operand
+    auto hidden_reg = [&](auto htc, auto rc, float acc_v, const frag4& mk, float inv_s, float rho_s, float* dst,
+                          auto to_x) {
+        constexpr int ht = decltype(htc)::value;
+        constexpr int r = decltype(rc)::value;
+        const float v = acc_v * mask_factor<(ht & 1) * 16 + r>(mk[ht >> 1], alpha);
+        const float t = v * inv_s;
+        if constexpr ((r & 3) == 0) q0 = t;
+        else if constexpr ((r & 3) == 1) q1 = t;
+        else if constexpr ((r & 3) == 2) q2 = t;
+        else store4(dst, 32 * ht, r, t);
+        const float pk = v * rho_s;
+        L.mrun = fmaxf(L.mrun, fabsf(pk));
+        if constexpr ((r & 1) == 0) pc = pk;
+        else {
+            float h0, l0, h1, l1;
+            split_trunc(pc, h0, l0);
+            split_trunc(pk, h1, l1);
+            constexpr int n = 2 * ht + (r >> 3), d = (r & 7) >> 1;
+            const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);
+            if constexpr (decltype(to_x)::value) { xh[n][d] = ph; xl[n][d] = pl; }
+            else { nh[n][d] = ph; nl[n][d] = pl; }
+        }
+    };
+    auto xyz_reg = [&](auto xtc, auto rc, float acc_v) {
+        constexpr int xt = decltype(xtc)::value;
+        constexpr int r = decltype(rc)::value;
+        const float t = acc_v * L.inv_sig;
+        if constexpr ((r & 3) == 0) q0 = t;
+        else if constexpr ((r & 3) == 1) q1 = t;
+        else if constexpr ((r & 3) == 2) q2 = t;
+        else store4(dx_cur, 32 * xt, r, t);
+    };
+
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        // accumulators rotate so that every body's LAST tile ends in accs[3]: that is where the next body's pending
+        // epilogue (u == 0) looks for it, whatever the tile count
+        constexpr int kOff = (4 - NU % 4) & 3;
+        f32x16& acc = accs[(u + kOff) & 3];
+        f32x16& prv = accs[u == 0 ? 3 : (u + kOff + 3) & 3];
+        static_for<0, NSTEP>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            f32x4 araw[2];
+            static_for<0, 2>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int Q = u * QPU + 2 * n + t;
+                constexpr int qc = Q % kHCQ;
+                if constexpr (qc == 0 && Q > 0) p.ck += 1;
+                if constexpr (qc == kHCQ / 2) {
+                    constexpr int room = (NQ - 1 - Q) / 2;
+                    pipe_sync_c<kHCQ, kHRing, (room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4)>(p);
+                }
+                if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) {
+                    constexpr int Qs = Q - (qc - kHCQ / 2);
+                    constexpr bool tail = (NQ - 1 - Qs) / 2 + 1 < kHCQ / 4;
+                    pipe_piece_c<(qc - kHCQ / 2) / 2, tail>(p);
+                }
+                lds_wait_frag_asm<(NQ - Q >= kPf ? kPf - 1 : NQ - Q - 1)>(pf[Q % kPf]);
+                araw[t] = pf[Q % kPf];
+                if constexpr (Q + kPf < NQ) {
+                    constexpr int Qn = Q + kPf;
+                    if constexpr (Qn % kHCQ == 0)
+                        rdbase[(Qn / kHCQ) & 1] = lane16 + (uint32_t)((ck0 + Qn / kHCQ) & (kHRing - 1)) * kHChunkBytes;
+                    issue_read(std::integral_constant<int, Qn>{});
+                }
+            });
+            const h8 a_hi = __builtin_bit_cast(h8, araw[0]);
+            const h8 a_lo = __builtin_bit_cast(h8, araw[1]);
+            frag4 bh_, bl_;
+            if constexpr (KIND == BW_HEAD) { bh_ = nh[n]; bl_ = nl[n]; }
+            else { bh_ = xh[n]; bl_ = xl[n]; }
+            const h8 b_hi = __builtin_bit_cast(h8, bh_), b_lo = __builtin_bit_cast(h8, bl_);
+            if constexpr (n == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, zero, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
+
+            // ---- deferred epilogues ----
+            if constexpr (u == 0 && PEND) {
+                if constexpr (n < 8) {           // previous body's hidden tile 7, a register pair per k-step
+                    hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
+                               mk_prev, L.inv_prev, L.rho_prev, d_prev, std::true_type{});
+                    hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n + 1>{},
+                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, d_prev, std::true_type{});
+                }
+                if constexpr (n == 8) {
+                    // this body's operand is complete: its peak fixes the scale of this body's outputs, and (in true
+                    // scale) is max|D| of the buffer the previous body wrote
+                    const float m_in = max_with_other_half(L.mrun);
+                    L.rho = pow2_to_peak(m_in);
+                    L.mrun = 0.f;
+                    atomicMax(lds_gmax() + gslot_prev, __float_as_uint(m_in * L.inv_sig));
+                    if (copy_tail) { xh[12] = nh[12]; xl[12] = nl[12]; }
+                }
+                if constexpr (n == 9) { if (copy_tail) { xh[13] = nh[13]; xl[13] = nl[13]; } }
+            }
+            if constexpr (u > 0) {
+                constexpr int pt = u - 1;        // the tile whose epilogue rides on this chain
+                if constexpr (pt < NX) {
+                    if constexpr (n < 16) xyz_reg(std::integral_constant<int, pt>{}, std::integral_constant<int, n>{}, prv[n]);
+                } else {
+                    constexpr int ht = pt - NX;
+                    if constexpr (NSTEP >= 16) {
+                        hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, n>{}, prv[n], mk_cur,
+                                   L.inv_sig, L.rho, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                    } else if constexpr (n < 8) {
+                        hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
+                                   mk_cur, L.inv_sig, L.rho, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                        hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n + 1>{},
+                                   prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, d_cur,
+                                   std::integral_constant<bool, KIND == BW_HEAD>{});
+                    }
+                }
+            }
+            // last tile of an in-place body: input fragment m-1 died with k-step m-1, outputs 0..11 are complete
+            if constexpr (KIND == BW_HID && u == NU - 1) {
+                if constexpr (n >= 1 && n - 1 < 12) { xh[n - 1] = nh[n - 1]; xl[n - 1] = nl[n - 1]; }
+            }
+        });
+    });
+    if constexpr (KIND == BW_XYZ) {      // end of the chain: the last encoding tile's epilogue has no chain to ride on
+        f32x16& last = accs[3];
+        static_for<0, 16>([&](auto rc) {
+            xyz_reg(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
+        });
+    }
+    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1>(p);
+    p.ck += 1;
+}
+
+template <bool DX>
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const uint32_t lane16 = kLdsRing + lane * 16;
+    const uint32_t cb_h = kLdsConst + h * 16;
+
+    const long long ntiles = a.Mp / 128;
+    if ((long long)blockIdx.x >= ntiles) return;
+
+    for (int i = tid; i < kBConstFloats / 4; i += 256)
+        reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + kBLdsGmax)[tid] = 0u;
+
+    Pipe p;
+    p.ck = 0;
+    p.src_next = 0;
+    p.n_chunks = DX ? kBStreamChunksDx : kBStreamChunks;
+    p.wbase = reinterpret_cast<const char*>(a.wstream);
+    p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
+    p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kHRing - 1; ++c) {
+        p.cur_src = p.wbase + (size_t)p.src_next * kHChunkBytes;
+        p.cur_dst = kLdsRing + c * kHChunkBytes + p.wave_lds;
+        p.src_next += 1;
+#pragma unroll
+        for (int q = 0; q < kHCQ / 4; ++q) dma_piece(p.cur_src, p.voff + q * kQuadBytes, p.cur_dst + q * kQuadBytes);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHCQ / 4) * (kHRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    frag4 xh[16], xl[16], nh[14], nl[14];
+    f32x16 accs[4];
+    const float alpha = a.alpha;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m = tile * 128 + wave * 32 + j;           // rows beyond M exist (padding) and carry zero Graw
+        // everything this tile reads from HBM, in one batch (a compiler-placed vmcnt wait drains the DMA ring once)
+        const f32x4 graw = *reinterpret_cast<const f32x4*>(a.graw + m * 4);
+        frag4 mq[9];
+#pragma unroll
+        for (int l = 0; l < 9; ++l) mq[l] = *(reinterpret_cast<const frag4*>(a.mask_ptr[8 - l]) + m * 2 + h);
+        // mq[0] = mask of h9 (layer 8's output), mq[1] = h8, ..., mq[8] = h1 (layer 0's output)
+
+        // ---- rgb head backward on the VALU: G9 = (W9 . d_rgb) * LeakyReLU'(h9), in fragment (k) order ----
+        float g9[64];
+        float mt = 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int t = n >> 1, s = n & 1;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 w0 = lds_read4(cb_h + (kBConstWrgb + 0 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                const f32x4 w1 = lds_read4(cb_h + (kBConstWrgb + 1 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                const f32x4 w2 = lds_read4(cb_h + (kBConstWrgb + 2 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int bit = (t & 1) * 16 + 8 * s + 4 * g + e;
+                    float v = w0[e] * graw[0] + w1[e] * graw[1] + w2[e] * graw[2];
+                    v = ((mq[0][t >> 1] >> bit) & 1u) ? v : alpha * v;
+                    o[e] = v;
+                    g9[n * 8 + g * 4 + e] = v;
+                    mt = fmaxf(mt, fabsf(v));
+                }
+                *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * 128 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
+            }
+        }
+        mt = max_with_other_half(mt);
+        atomicMax(lds_gmax() + 0, __float_as_uint(mt));
+        const float m_true = fmaxf(mt, fabsf(graw[3]));
+        BwdLane L;
+        const float sig = pow2_to_peak(m_true);
+        L.inv_sig = pow2_inverse(sig);
+        L.rho = pow2_to_peak(m_true * sig);
+        L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
+        L.mrun = 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float h0, l0, h1, l1;
+                split_trunc(g9[n * 8 + e] * sig, h0, l0);
+                split_trunc(g9[n * 8 + e + 1] * sig, h1, l1);
+                nh[n][e >> 1] = pack_h2(h0, h1);
+                nl[n][e >> 1] = pack_h2(l0, l1);
+            }
+        }
+        {   // the sigma head's rank-1 term rides as a 9th k-step: element 0 of lane half 0 = d_sigma
+            float h0, l0;
+            split_trunc(h ? 0.f : graw[3] * sig, h0, l0);
+            nh[8] = frag4{pack_h2(h0, 0.f), 0u, 0u, 0u};
+            nl[8] = frag4{pack_h2(l0, 0.f), 0u, 0u, 0u};
+        }
+
+        const long long off256 = m * 256 + 4 * h;
+        float* d_prev = nullptr;
+        float* d_cur = a.d_ptr[7] + off256;
+        float* dxa = DX ? a.dx_ptr[0] + m * kBwdXyzLd + 4 * h : nullptr;
+        float* dxb = DX ? a.dx_ptr[1] + m * kBwdXyzLd + 4 * h : nullptr;
+        frag4 mk_prev = mq[1], mk_cur = mq[1];
+        bwd_body<BW_HEAD, 0, false>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
+                                    nh, nl);
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {         // body of layer l: consumes D_l, produces D_(l-1)
+            // rotate the per-lane scale state and the mask queue (mq[1] is always the mask of the operand just produced)
+            L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
+            L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
+            mk_prev = mk_cur;
+#pragma unroll
+            for (int i = 1; i < 8; ++i) mq[i] = mq[i + 1];
+            mk_cur = mq[1];
+            d_prev = d_cur;
+            d_cur = a.d_ptr[l - 1] + off256;
+            const int gslot_prev = 8 - l;          // slot k <-> D_(8-k)
+            if (DX && l == 4)
+                bwd_body<BW_HID, DX ? 2 : 0, true>(p, lane16, alpha, L, true, d_prev, d_cur, dxa, mk_prev, mk_cur,
+                                                   gslot_prev, accs, xh, xl, nh, nl);
+            else
+                bwd_body<BW_HID, 0, true>(p, lane16, alpha, L, l != 7, d_prev, d_cur, nullptr, mk_prev, mk_cur, gslot_prev,
+                                          accs, xh, xl, nh, nl);
+        }
+        L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
+        L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
+        if constexpr (DX) {
+            bwd_body<BW_XYZ, 2, true>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, 8, accs, xh, xl, nh, nl);
+        } else {
+            // flush: D0's last tile has no chain to ride on; nothing is packed any more
+            f32x16& last = accs[3];
+            float tmax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int bit = 16 + r + e;
+                    const float v = last[r + e] * (((mk_cur[3] >> bit) & 1u) ? 1.0f : alpha) * L.inv_prev;
+                    o[e] = v;
+                    tmax = fmaxf(tmax, fabsf(v));
+                }
+                *reinterpret_cast<f32x4*>(d_cur + 32 * 7 + 8 * (r >> 2)) = o;
+            }
+            // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
+            tmax = fmaxf(tmax, L.mrun * L.inv_sig);
+            atomicMax(lds_gmax() + 8, __float_as_uint(max_with_other_half(tmax)));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 9 && a.gmax) {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(smem + kBLdsGmax)[tid];
+        unsigned* slot = a.gmax + 64 * tid + (blockIdx.x & 63);
+        if (v > *slot) atomicMax(slot, v);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_kernel(const MlpBwdArgs a) { mlp_bwd_body<false>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true>(a); }
+
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, int num_cus, hipStream_t stream) {
+    if (a.Mp <= 0) return;
+    const long long ntiles = a.Mp / 128;
+    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    if (dx) hipLaunchKernelGGL(mlp_bwd_f16x3_dx_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    else hipLaunchKernelGGL(mlp_bwd_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+}
+
+void mlp_bwd_f16x3_set_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_f16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_f16x3_dx_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The backward stream as an index map (host): idx[slot] = 2 * (src + 1) + is_lo, 0 = padding; src = index into the
+// blob (Keras get_weights() order).  Re-packed on the device after every optimizer step by repack_bwd_kernel.
+// ------------------------------------------------------------------------------------------------
+void build_bwd_gather(int n_angles, bool dx, int32_t* idx /* kBwdStreamBytes / 2 entries */) {
+    memset(idx, 0, (kBwdStreamBytes / 2) * sizeof(int32_t));
+    const int kd = 256 + 8 * (n_angles + 1);
+    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
+    long long koff[11], off = 0;
+    for (int i = 0; i < 11; ++i) { koff[i] = off; off += (long long)shapes[i][0] * shapes[i][1] + shapes[i][1]; }
+    size_t chunk = 0;
+    // one body: NU tiles x NSTEP k-steps; src(u, i, n, e, h) gives the blob index of A[i][k] or -1
+    auto emit = [&](int NU, int NSTEP, auto src) {
+        const long long b0 = (long long)chunk * (kHChunkBytes / 2);
+        for (int u = 0; u < NU; ++u)
+            for (int n = 0; n < NSTEP; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const long long s = src(u, lane & 31, n, e, lane >> 5);
+                        if (s < 0) continue;
+                        const long long q = (long long)(u * NSTEP + n) * 2;
+                        idx[b0 + (q + 0) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1));
+                        idx[b0 + (q + 1) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1) + 1);
+                    }
+        chunk += (NU * NSTEP * 2 + kHCQ - 1) / kHCQ;
+    };
+    // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step)
+    emit(8, kBStepsHead, [&](int u, int i, int n, int e, int h) -> long long {
+        if (n < 8) return koff[8] + (long long)(32 * u + i) * 128 + frag_feature(n, e, h);
+        return (e == 0 && h == 0) ? koff[10] + (32 * u + i) : -1;
+    });
+    auto hidden = [&](int l, int row0) {
+        return [=](int u, int i, int n, int e, int h) -> long long {
+            return koff[l] + (long long)(row0 + 32 * u + i) * 256 + frag_feature(n, e, h);
+        };
+    };
+    auto with_xyz = [&](int l, int nx, int row0) {       // nx encoding tiles first, then (for layer 4) the hidden rows
+        return [=](int u, int i, int n, int e, int h) -> long long {
+            if (u < nx) {
+                const int row = 32 * u + i;
+                return row < kXyzDim ? koff[l] + (long long)row * 256 + frag_feature(n, e, h) : -1;
+            }
+            return koff[l] + (long long)(row0 + 32 * (u - nx) + i) * 256 + frag_feature(n, e, h);
+        };
+    };
+    for (int l = 7; l >= 5; --l) emit(8, 16, hidden(l, 0));
+    if (dx) emit(10, 16, with_xyz(4, 2, kXyzDim));
+    else emit(8, 16, hidden(4, kXyzDim));
+    for (int l = 3; l >= 1; --l) emit(8, 16, hidden(l, 0));
+    if (dx) emit(2, 16, with_xyz(0, 2, 0));
+}
+
+__global__ void repack_bwd_kernel(const float* __restrict__ blob, const int32_t* __restrict__ idx,
+                                  uint16_t* __restrict__ stream, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t t = idx[i];
+    uint16_t out = 0;
+    if (t != 0) {
+        const float w = blob[(t >> 1) - 1];
+        const _Float16 hi = (_Float16)w;
+        const _Float16 v = (t & 1) ? (_Float16)(w - (float)hi) : hi;
+        out = __builtin_bit_cast(uint16_t, v);
+    }
+    stream[i] = out;
+}
+
+void launch_repack_bwd(const float* blob, const int32_t* idx, void* stream, hipStream_t s) {
+    const size_t n = kBwdStreamBytes / 2;
+    hipLaunchKernelGGL(repack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blob, idx,
+                       reinterpret_cast<uint16_t*>(stream), n);
+}
+
+}  // namespace nerf

@@ -13,31 +13,12 @@
 //   * the sigma head (280 -> 1) rides the MFMA as a 5th output tile of layer 8 (its inputs only
 //     exist as fp16 hi/lo fragments); the rgb head (128 -> 3) stays on the VALU in fp32.
 // Measured accuracy (tests/test_gpu_parity.py): final RGB within 1e-4 of the fp32 oracle.
-#include "mlp_common.h"
+#include "mlp_f16_frag.h"
 
 #include <math.h>
 #include <string.h>
 
 namespace nerf {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef uint32_t frag4 __attribute__((ext_vector_type(4)));   // one fp16 fragment = 4 dwords of 2 halfs
-
-// asm LDS read of one fragment into an AGPR quad, and the counted wait that retires it (see layer_body_h)
-template <int OFF>
-__device__ __forceinline__ void lds_read_frag_asm(f32x4& dst, uint32_t base) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(base), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_frag_asm(f32x4& reg) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(reg) : "n"(N) : "memory");
-}
-
-__device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // RNE; v_cvt_pk_f16_f32
-    const h2 t = {(_Float16)a, (_Float16)b};
-    return __builtin_bit_cast(uint32_t, t);
-}
 
 #ifdef NERF_STAMPS
 __device__ unsigned long long g_stamps_h[16];
@@ -52,15 +33,11 @@ constexpr int kHQpuHid = 2 * kHStepsHid;
 constexpr int kHQpuSkip = kHQpuPE + kHQpuHid;
 constexpr int kHQpuLast = kHQpuHid + 2 * kHStepsDir;
 constexpr int kHTilesLast = 5;    // 4 x 32 features of layer 8 + the sigma row
-constexpr int kHCQ = 32;          // quads per chunk (32 KiB)
-constexpr int kHRing = 4;         // ring slots (128 KiB)
-constexpr int kHChunkBytes = kHCQ * kQuadBytes;
 constexpr int kHChunksPE = (8 * kHQpuPE + kHCQ - 1) / kHCQ;          // 2
 constexpr int kHChunksHid = (8 * kHQpuHid) / kHCQ;                   // 8
 constexpr int kHChunksSkip = (8 * kHQpuSkip + kHCQ - 1) / kHCQ;      // 10
 constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + kHCQ - 1) / kHCQ;   // 6
 constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 66
-static_assert(kHRing * kHChunkBytes == kRingBytes, "fp16 ring must fill the shared LDS carve");
 // single-pass mode: its own stream with the hi fragments only (one quad per k-step)
 constexpr int kFChunksPE = (8 * kHStepsPE + kHCQ - 1) / kHCQ;                          // 1
 constexpr int kFChunksHid = (8 * kHStepsHid) / kHCQ;                                   // 4
@@ -79,15 +56,6 @@ constexpr int kHConstFloats = 2608;
 static_assert(kHStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16, "stream size mismatch");
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
 
-// fp32 -> (hi, lo) with hi = the top 11 significand bits (exact in fp16) and lo = y - hi (exact in
-// fp32, then rounded to fp16): |lo| <= 2^-10 |y|, total representation error <= 2^-21 |y|.  Costs two
-// plain VALU ops (v_and, v_sub) instead of a v_cvt round trip: beside the fp16 MFMA, conversions and
-// moves are "8-cycle" instructions, plain arithmetic is nearly free (tools/microbench/valu_cost_f16.hip).
-__device__ __forceinline__ void split_trunc(float y, float& hi_f, float& lo_f) {
-    hi_f = __uint_as_float(__float_as_uint(y) & 0xFFFFE000u);
-    lo_f = y - hi_f;
-}
-
 // One dense layer on the fp16 matrix cores, u-outer (one accumulator chain per 32-wide output tile).
 // The epilogue of a tile (bias, LeakyReLU, hi/lo split, fp16 pack) is dealt out ONE accumulator
 // register per k-step over the NEXT tile's chain -- also across layer boundaries (PENDING: the
@@ -98,9 +66,14 @@ __device__ __forceinline__ void split_trunc(float y, float& hi_f, float& lo_f) {
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
 // STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
 // of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store.
+// It also records the LeakyReLU' masks the fused backward (mlp_bwd_f16x3.hip) multiplies by: one bit per activation
+// (1 = positive), bit 16 ut + r of the lane's 128-bit word mk_cur = accumulator register r of output tile ut, i.e.
+// exactly the layout in which the backward's accumulators hold the gradient of that activation; one 16-byte store
+// per lane and layer (32 B per sample row instead of re-reading the 1 KB stash row for its signs).
 template <int BODY, bool PENDING, bool FAST, bool STASH = false>
 __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
-                                             float alpha, float* st_prev, float* st_cur, f32x16 (&accs)[4],
+                                             float alpha, float* st_prev, float* st_cur, frag4* mk_prev_ptr,
+                                             frag4* mk_cur_ptr, frag4& mk_prev, frag4& mk_cur, f32x16 (&accs)[4],
                                              frag4 (&xh)[16], frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14],
                                              const frag4 (&peh)[3], const frag4 (&pel)[3], const frag4 (&dh)[2],
                                              const frag4 (&dl)[2], float (&xc)[64], float& sigma_raw) {
@@ -171,7 +144,13 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         constexpr int n = 2 * ut + (r >> 3), e = r & 7;
-        if constexpr (STASH) stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
+        if constexpr (STASH) {
+            stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
+            constexpr int sh = (ut & 1) * 16 + r;
+            const uint32_t bits = (y0 > 0.f ? (1u << sh) : 0u) | (y1 > 0.f ? (2u << sh) : 0u);
+            if constexpr (decltype(pend_sel)::value) mk_prev[ut >> 1] |= bits;
+            else mk_cur[ut >> 1] |= bits;
+        }
         if constexpr (FAST) {
             const uint32_t ph = pack_h2(y0, y1);                          // round to fp16, no lo part
             if constexpr (decltype(dest_sel)::value) xh[n][e >> 1] = ph;
@@ -264,12 +243,14 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                     if constexpr (STASH) {      // layer 8's outputs (128 features) go to the stash in fours as well
                         if constexpr ((n & 1) == 0) ycarry = y;
                         else stash4(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, st_cur);
+                        mk_cur[et >> 1] |= y > 0.f ? (1u << ((et & 1) * 16 + n)) : 0u;
                     }
                 }
                 else if constexpr ((n & 1) == 0) ycarry = y;
                 else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, std::false_type{}, std::false_type{});
             }
             if constexpr (u == 0 && PENDING) {
+                if constexpr (STASH && n == 8) { if (mk_prev_ptr) *mk_prev_ptr = mk_prev; }   // that layer's mask word is complete
                 // previous layer's tile 6 sits complete in nh/nl[12..13]; its k-steps are long retired
                 if constexpr (n == 8) { xh[12] = nh[12]; xl[12] = nl[12]; }
                 if constexpr (n == 9) { xh[13] = nh[13]; xl[13] = nl[13]; }
@@ -300,6 +281,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     if constexpr (BODY == BODY_LAST) {
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
         sigma_raw = accs[(NU - 1) & 3][0];
+        if constexpr (STASH) { if (mk_cur_ptr) *mk_cur_ptr = mk_cur; }   // layer 8 (128 features): all four tiles are finished
     }
     if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1>(p);
     p.ck += 1;
@@ -428,26 +410,37 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             if constexpr (!STASH) return nullptr;
             else return a.st_ptr[l] + (tile * 128 + wave * 32 + j) * (long long)a.st_ld[l] + 4 * h;
         };
+        auto mk_of = [&](int l) -> frag4* {
+            if constexpr (!STASH) return nullptr;
+            else return a.mask_ptr[l] ? reinterpret_cast<frag4*>(a.mask_ptr[l]) + (tile * 128 + wave * 32 + j) * 2 + h
+                                      : nullptr;      // no record wanted (layer-by-layer backward)
+        };
+        frag4 mk_prev = {0u, 0u, 0u, 0u}, mk_cur = {0u, 0u, 0u, 0u};
+        frag4 *mk_prev_ptr = nullptr, *mk_cur_ptr = mk_of(0);
         float* st_prev = nullptr;
         float* st_cur = st_of(0);
         STAMP(t1); acc_t[0] += t1 - t0;
-        layer_body_h<BODY_PE, false, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        layer_body_h<BODY_PE, false, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             st_prev = st_cur;
             st_cur = st_of(l);
+            mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(l);
+            mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
             if (l == 4) {
-                layer_body_h<BODY_SKIP, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_SKIP, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
             } else {
-                layer_body_h<BODY_HID, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+                layer_body_h<BODY_HID, true, FAST, STASH>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
         st_prev = st_cur;
         st_cur = st_of(8);
-        layer_body_h<BODY_LAST, true, FAST, STASH>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, st_prev, st_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(8);
+        mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
+        layer_body_h<BODY_LAST, true, FAST, STASH>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         STAMP(t1); acc_t[4] += t1 - t0;
 
         // rgb head (128 -> 3) on the VALU in fp32

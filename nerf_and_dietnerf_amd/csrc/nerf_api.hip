@@ -269,6 +269,7 @@ int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out) {
     }
     mlp_fp32_set_attributes();
     mlp_f16x3_set_attributes();
+    mlp_bwd_f16x3_set_attributes();
     *out = c;
     return 0;
 }

@@ -70,6 +70,8 @@ struct MlpArgs {
     // row-major with leading dimension st_ld[l] (rows padded to a multiple of 128); unused (null) when rendering
     float* st_ptr[9];
     int st_ld[9];
+    // ... and where the LeakyReLU' mask bits of layer l's output go: one uint4 per (row, lane half), see mlp_f16x3.hip
+    uint32_t* mask_ptr[9];
 };
 
 // mlp_fp32.hip
@@ -88,6 +90,25 @@ void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* str
 void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
 void pack_weights_f16(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16Hi*/, float* const_out /*kConstFloats*/);
+
+// mlp_bwd_f16x3.hip -- the trainer's fused data-gradient chain (the stash forward's counterpart)
+constexpr size_t kBwdStreamBytes = size_t(65) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles
+constexpr int kBwdXyzLd = 64;                                      // floats per row of an encoding-gradient buffer
+struct MlpBwdArgs {
+    const void* wstream;     // backward operand stream of one network (build_bwd_gather / launch_repack_bwd)
+    const float* wconst;     // the forward kernel's constant block (rgb head weights are read from it)
+    const float* graw;       // (Mp, 4) gradient w.r.t. the raw network output [r, g, b, sigma]; padding rows zero
+    const uint32_t* mask_ptr[9];   // LeakyReLU' bit records of layers 0..8, written by the stash forward
+    float* d_ptr[9];         // d_ptr[l], l = 0..7: (Mp, 256) gradient w.r.t. layer l's pre-activation; d_ptr[8]: G9 (Mp, 128)
+    float* dx_ptr[2];        // dx variant: (Mp, 64) gradient w.r.t. the xyz encoding through layer 4 / through layer 0
+    unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k)
+    long long Mp;            // rows, multiple of 128
+    float alpha;
+};
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, int num_cus, hipStream_t stream);
+void mlp_bwd_f16x3_set_attributes();
+void build_bwd_gather(int n_angles, bool dx, int32_t* idx /* kBwdStreamBytes / 2 */);
+void launch_repack_bwd(const float* blob, const int32_t* idx, void* stream, hipStream_t s);
 
 // aux_kernels.hip
 void launch_raygen(const float c2w_host[16], float fov, int H, int W,

@@ -30,12 +30,17 @@ struct TNet {
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
     void* fstream = nullptr;       // fused forward (f16x3 stash kernel): operand stream + constants, re-packed on device
     float* fcst = nullptr;
+    void* bstream = nullptr;       // fused backward (mlp_bwd_f16x3): transposed operand stream, re-packed on device
+    bool bdx = false;              // ... built with the encoding tiles (the fine network under sampler_gradient)
     int n_layers = 11;             // 11: xyz + view-direction network; 12: xyz-only network (n_angles_for_model = 0)
     TLayer L[12];
 };
 
 struct TPass {                      // activations of one pass, kept from forward to backward
     DevBuf C4, C8, H1, H2, H3, H5, H6, H7, H8b, H9, raw, T, w, rgb, z;   // H8b: xyz-only network's extra layer
+    // fused backward: LeakyReLU' bit records of layers 0..8 (32 B per row and layer, written by the stash forward),
+    // the pre-activation gradients D[0..7] (Mp x 256) and G9 = D[8] (Mp x 128), the two encoding-gradient parts
+    DevBuf masks, D[9], dxa, dxb;
 };
 
 struct TrainState {
@@ -43,6 +48,8 @@ struct TrainState {
     bool training = false;          // false: created only to serve the layer-wise forward of the xyz-only network
     bool fused_forward = false;     // forward pass on the fused split-fp16 kernel with activation stash (n_angles > 0)
     int32_t *sidx = nullptr, *cidx = nullptr;   // device gather tables of the fused kernel's stream / constants
+    bool fused_backward = false;    // data gradients by the fused chain kernel (needs the fused forward's mask records)
+    int32_t* bidx[2] = {nullptr, nullptr};      // gather tables of the backward stream: [0] plain, [1] with encoding tiles
     long long step = 0;
     size_t nblob = 0;
     TNet net[2];
@@ -86,6 +93,7 @@ void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0
 
 int relayout_net(nerf_ctx* c, TNet& n) {
     if (n.fstream) launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->stream);
+    if (n.bstream) launch_repack_bwd(n.blob, c->train->bidx[n.bdx ? 1 : 0], n.bstream, c->stream);
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
@@ -122,6 +130,18 @@ int ensure_fused(nerf_ctx* c, TrainState* t, TNet& n) {
     }
     if (!n.fstream) HIP_OK(hipMalloc(&n.fstream, kStreamBytesF16));
     if (!n.fcst) HIP_OK(hipMalloc((void**)&n.fcst, kConstBytes));
+    if (t->fused_backward && t->training) {
+        // the fine network's chain also produces the gradient w.r.t. the xyz encoding when the sampler is differentiated
+        n.bdx = (&n == &t->net[1]) && t->cfg.sampler_gradient != 0;
+        int32_t*& bi = t->bidx[n.bdx ? 1 : 0];
+        if (!bi) {
+            std::vector<int32_t> idx(kBwdStreamBytes / 2);
+            build_bwd_gather(c->cfg.n_angles, n.bdx, idx.data());
+            HIP_OK(hipMalloc((void**)&bi, idx.size() * sizeof(int32_t)));
+            HIP_OK(hipMemcpy(bi, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!n.bstream) HIP_OK(hipMalloc(&n.bstream, kBwdStreamBytes));
+    }
     return 0;
 }
 
@@ -169,6 +189,13 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     r |= ensure(c, p.w, d.M * f);
     r |= ensure(c, p.rgb, d.N * 3 * f);
     r |= ensure(c, p.z, d.M * f);
+    if (c->train && c->train->fused_backward && c->train->training) {
+        r |= ensure(c, p.masks, (size_t)9 * d.Mp * 32);
+        for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * 256 * f);
+        r |= ensure(c, p.D[8], d.Mp * 128 * f);
+        r |= ensure(c, p.dxa, d.Mp * kBwdXyzLd * f);
+        r |= ensure(c, p.dxb, d.Mp * kBwdXyzLd * f);
+    }
     return r;
 }
 
@@ -222,7 +249,10 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
         float* dst[9] = {(float*)p.H1.p, (float*)p.H2.p, (float*)p.H3.p, (float*)p.C4.p, (float*)p.H5.p,
                          (float*)p.H6.p, (float*)p.H7.p, (float*)p.C8.p, (float*)p.H9.p};
         const int ld[9] = {256, 256, 256, kLdC4, 256, 256, 256, kLdC8, 128};
-        for (int i = 0; i < 9; ++i) { a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i]; }
+        for (int i = 0; i < 9; ++i) {
+            a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i];
+            a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
+        }
         launch_mlp_f16x3_stash(a, c->num_cus, c->stream);
     } else {
         forward_layers(c, n, p, d.Mp, raw);
@@ -298,10 +328,40 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
           *dA0 = (float*)t->dA0.p;
     const bool dx = d_z != nullptr;
     // gm[k]: bits of max|G| of the gradient buffer produced k-th in this pass (scale of the split-fp16 weight gradient)
-    unsigned* gm = t->wgrad_f16 ? (unsigned*)t->gmax.p : nullptr;      // exact-fp32 weight gradients need no scale
+    // exact-fp32 weight gradients need no scale (but the fused chain always reports its maxima)
+    unsigned* gm = t->wgrad_f16 || t->fused_backward ? (unsigned*)t->gmax.p : nullptr;
     if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
     auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
     auto DS = [&](int l) -> const TLayer* { return t->dgrad_f16 && gm ? &n.L[l] : nullptr; };   // pre-split W of layer l
+    if (t->fused_backward && n.bstream && n.fcst && p.masks.p && gm) {
+        // ONE kernel for the whole data-gradient chain (mlp_bwd_f16x3.hip): the gradient stays on the lane from layer to
+        // layer; every D_l is written once for the weight-gradient GEMMs below, with max|D_l| in the same gmax slots
+        MlpBwdArgs b{};
+        b.wstream = n.bstream; b.wconst = n.fcst; b.graw = Graw; b.gmax = gm; b.Mp = Mp; b.alpha = c->cfg.leaky_relu_alpha;
+        for (int l = 0; l < 9; ++l) {
+            b.mask_ptr[l] = (const uint32_t*)p.masks.p + (size_t)l * Mp * 8;
+            b.d_ptr[l] = (float*)p.D[l].p;
+        }
+        b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
+        launch_mlp_bwd_f16x3(b, n.bdx, c->num_cus, c->stream);
+        wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
+        wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
+        wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], 128, 128, 0, Mp, GM(0));
+        wgrad(c, t, n, 7, H7, 256, b.d_ptr[7], 256, 256, 0, Mp, GM(1));
+        wgrad(c, t, n, 6, H6, 256, b.d_ptr[6], 256, 256, 0, Mp, GM(2));
+        wgrad(c, t, n, 5, H5, 256, b.d_ptr[5], 256, 256, 0, Mp, GM(3));
+        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], 256, 256, 0, Mp, GM(4));
+        wgrad(c, t, n, 3, H3, 256, b.d_ptr[3], 256, 256, 0, Mp, GM(5));
+        wgrad(c, t, n, 2, H2, 256, b.d_ptr[2], 256, 256, 0, Mp, GM(6));
+        wgrad(c, t, n, 1, H1, 256, b.d_ptr[1], 256, 256, 0, Mp, GM(7));
+        wgrad(c, t, n, 0, C4 + 256, kLdC4, b.d_ptr[0], 256, 256, 0, Mp, GM(8));
+        if (dx) {
+            if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
+            launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
+        }
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     if (n.n_layers == 11) {
         wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
@@ -338,7 +398,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     wgrad(c, t, n, 0, C4 + 256, kLdC4, Gb, 256, 256, 0, Mp, GM(8));
     if (dx) {
         dgrad_xyz(c, Gb, n.L[0].W, dA0, Mp, true);
-        launch_pe_bwd(dA0, o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
+        launch_pe_bwd(dA0, nullptr, o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -468,15 +528,19 @@ void train_free(nerf_ctx* c) {
         if (n.mats) (void)hipFree(n.mats);
         if (n.fstream) (void)hipFree(n.fstream);
         if (n.fcst) (void)hipFree(n.fcst);
+        if (n.bstream) (void)hipFree(n.bstream);
     }
     if (t->sidx) (void)hipFree(t->sidx);
     if (t->cidx) (void)hipFree(t->cidx);
+    for (int32_t* bi : t->bidx) if (bi) (void)hipFree(bi);
     TPass* passes[] = {&t->pass[0], &t->pass[1], &t->infer};
     for (TPass* pp : passes) {
         TPass& p = *pp;
         DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
                         &p.rgb, &p.z};
         for (DevBuf* b : bs) free_buf(*b);
+        free_buf(p.masks); free_buf(p.dxa); free_buf(p.dxb);
+        for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
                     &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax};
@@ -575,6 +639,10 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     t->wgrad_wide = !(ww && strcmp(ww, "128") == 0);
     const char* dg = getenv("NERF_TRAIN_DGRAD");
     t->dgrad_f16 = t->wgrad_f16 && !(dg && strcmp(dg, "fp32") == 0);     // needs the max tracking of the f16 path
+    // data gradients by the fused chain kernel (the stash forward's counterpart) unless NERF_TRAIN_BACKWARD=layers asks
+    // for the layer-by-layer GEMMs; it reads the forward's mask records, so it needs the fused forward
+    const char* bw = getenv("NERF_TRAIN_BACKWARD");
+    t->fused_backward = t->fused_forward && t->dgrad_f16 && !(bw && strcmp(bw, "layers") == 0);
     for (int w = 0; w < 2; ++w) {
         if (!c->net[w].loaded) continue;
         if (!t->net[w].present) {

@@ -79,8 +79,8 @@ void launch_composite_bwd(const float* raw, const float* z, const float* T, long
                           const float* d_w_ext, float* Graw, float* d_z, hipStream_t s);
 void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,
                      long long M, float alpha, float* G9, unsigned* gmax, hipStream_t s);
-void launch_pe_bwd(const float* dA0, const float* o, const float* d, const float* z, long long N, int S, float* d_z,
-                   hipStream_t s);
+void launch_pe_bwd(const float* dA0, const float* dA0b /* added to dA0, or null */, const float* o, const float* d,
+                   const float* z, long long N, int S, float* d_z, hipStream_t s);
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
                            uint64_t seed, long long ray_base, const float* d_zf, float* d_w, hipStream_t s);
 size_t sample_pdf_bwd_lds_bytes(int S, int Sf);

@@ -1013,7 +1013,8 @@ void launch_head_bwd(const float* Graw, const float* W9, const float* H9, long l
 // ------------------------------------------------------------------------------------------------
 // positional-encoding backward + sample_along_rays backward: d_z[m] += sum_c dL/dp_c * dir_c
 // ------------------------------------------------------------------------------------------------
-__global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __restrict__ o, const float* __restrict__ d,
+__global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __restrict__ dA0b /* second part to add, or null */,
+                              const float* __restrict__ o, const float* __restrict__ d,
                               const float* __restrict__ z, long long M, int S, float* __restrict__ d_z) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
@@ -1024,7 +1025,9 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
     const float p[3] = {__fadd_rn(oo.x, __fmul_rn(dd.x, zz)), __fadd_rn(oo.y, __fmul_rn(dd.y, zz)),
                         __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
     const float dv[3] = {dd.x, dd.y, dd.z};
-    const float* g = dA0 + m * kXyzPad;
+    float g[33];                                   // the 33-wide xyz encoding (3 x (1 + 2 * 5))
+#pragma unroll
+    for (int i = 0; i < 33; ++i) g[i] = dA0[m * kXyzPad + i] + (dA0b ? dA0b[m * kXyzPad + i] : 0.f);
     float acc = 0.f;
     for (int c = 0; c < 3; ++c) {
         float dp = g[c * 11];
@@ -1039,11 +1042,11 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
     d_z[m] += acc;
 }
 
-void launch_pe_bwd(const float* dA0, const float* o, const float* d, const float* z, long long N, int S, float* d_z,
-                   hipStream_t s) {
+void launch_pe_bwd(const float* dA0, const float* dA0b, const float* o, const float* d, const float* z, long long N, int S,
+                   float* d_z, hipStream_t s) {
     const long long M = N * S;
     if (M <= 0) return;
-    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, dA0, o, d, z, M, S, d_z);
+    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, dA0, dA0b, o, d, z, M, S, d_z);
 }
 
 // ------------------------------------------------------------------------------------------------
