@@ -408,7 +408,7 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
         // stash rows of this lane's sample (rows beyond M exist: the buffers are padded to whole 128-row tiles)
         auto st_of = [&](int l) -> float* {
             if constexpr (!STASH) return nullptr;
-            else return a.st_ptr[l] + (tile * 128 + wave * 32 + j) * (long long)a.st_ld[l] + 4 * h;
+            else return a.st_ptr[l] + (a.diag_wrap ? (long long)(blockIdx.x * 8 + (j & 7)) : tile * 128 + wave * 32 + j) * (long long)a.st_ld[l] + 4 * h;
         };
         auto mk_of = [&](int l) -> frag4* {
             if constexpr (!STASH) return nullptr;

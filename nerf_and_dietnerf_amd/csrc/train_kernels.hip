@@ -1025,12 +1025,21 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
     const float p[3] = {__fadd_rn(oo.x, __fmul_rn(dd.x, zz)), __fadd_rn(oo.y, __fmul_rn(dd.y, zz)),
                         __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
     const float dv[3] = {dd.x, dd.y, dd.z};
-    float g[33];                                   // the 33-wide xyz encoding (3 x (1 + 2 * 5))
+    // the encoding gradient may come in two parts (fused backward: through layer 4 and through layer 0)
+    const float* ga = dA0 + m * kXyzPad;
+    const float* gb = dA0b ? dA0b + m * kXyzPad : nullptr;
+    float g[36];
 #pragma unroll
-    for (int i = 0; i < 33; ++i) g[i] = dA0[m * kXyzPad + i] + (dA0b ? dA0b[m * kXyzPad + i] : 0.f);
+    for (int q = 0; q < 9; ++q) {                  // 33 floats, read as 9 float4 (rows are 64 floats: no overrun)
+        float4 v = reinterpret_cast<const float4*>(ga)[q];
+        if (gb) { const float4 w = reinterpret_cast<const float4*>(gb)[q]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+    }
     float acc = 0.f;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         float dp = g[c * 11];
+#pragma unroll
         for (int k = 0; k < 5; ++k) {
             const float f = kPi * (float)(1 << k);
             const float th = __fmul_rn(p[c], f);
