@@ -54,6 +54,26 @@ constexpr int kHConstBHead = 2592;    // b_r, b_g, b_b, (unused)
 constexpr int kHConstFloats = 2608;
 
 static_assert(kHStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16, "stream size mismatch");
+// xyz-only network (n_angles_for_model = 0, src/NeRF.py:248-288): ... -> h8 -> [sigma | dense 256] -> dense 128 -> rgb.
+// Its tail replaces BODY_LAST by two bodies: BODY_HIDSIG (the extra 256-wide layer with the sigma row as a LEADING 9th
+// tile: sigma reads h8, this body's input) and BODY_LAST0 (256 -> 128, no direction k-steps, no sigma tile).
+constexpr int kXChunksHidSig = (9 * kHQpuHid) / kHCQ;                   // 9
+constexpr int kXChunksLast0 = (4 * kHQpuHid) / kHCQ;                    // 4
+constexpr int kXStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kXChunksHidSig + kXChunksLast0;   // 73
+constexpr int kXFChunksHidSig = (9 * kHStepsHid + kHCQ - 1) / kHCQ;     // 5
+constexpr int kXFChunksLast0 = (4 * kHStepsHid) / kHCQ;                 // 2
+constexpr int kXFStreamChunks = kFChunksPE + 6 * kFChunksHid + kFChunksSkip + kXFChunksHidSig + kXFChunksLast0;   // 37
+static_assert(kXStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16Xyz, "xyz-only stream size mismatch");
+static_assert(kXFStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16HiXyz, "xyz-only hi stream size mismatch");
+// constant region of the xyz-only variant (floats): 8 x 256 biases as above, then
+constexpr int kXConstBiasSig = 2048;  // 32: row 0 = sigma bias (the leading tile of BODY_HIDSIG)
+constexpr int kXConstBias8 = 2080;    // 256: the extra hidden layer
+constexpr int kXConstBias9 = 2336;    // 128
+constexpr int kXConstWrgb = 2464;     // [3][128]
+constexpr int kXConstBHead = 2848;    // b_r, b_g, b_b, (unused)
+constexpr int kXConstFloats = 2864;
+static_assert(kXConstFloats <= kConstFloats, "xyz-only constants must fit the shared LDS carve");
+enum { BODY_HIDSIG = 4, BODY_LAST0 = 5 };
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
 
 // One dense layer on the fp16 matrix cores, u-outer (one accumulator chain per 32-wide output tile).
@@ -70,16 +90,19 @@ static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the share
 // (1 = positive), bit 16 ut + r of the lane's 128-bit word mk_cur = accumulator register r of output tile ut, i.e.
 // exactly the layout in which the backward's accumulators hold the gradient of that activation; one 16-byte store
 // per lane and layer (32 B per sample row instead of re-reading the 1 KB stash row for its signs).
-template <int BODY, bool PENDING, bool FAST, bool STASH = false>
+// ROT rotates the four accumulators: tile u works in accs[(u + ROT) & 3] and a PENDING tile is looked for in
+// accs[(ROT + 3) & 3]; every body but BODY_LAST0 (which follows the 9-tile BODY_HIDSIG) uses ROT = 0.
+template <int BODY, bool PENDING, bool FAST, bool STASH = false, int ROT = 0>
 __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes,
                                              float alpha, float* st_prev, float* st_cur, frag4* mk_prev_ptr,
                                              frag4* mk_cur_ptr, frag4& mk_prev, frag4& mk_cur, f32x16 (&accs)[4],
                                              frag4 (&xh)[16], frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14],
                                              const frag4 (&peh)[3], const frag4 (&pel)[3], const frag4 (&dh)[2],
                                              const frag4 (&dl)[2], float (&xc)[64], float& sigma_raw) {
-    constexpr int NU = BODY == BODY_LAST ? kHTilesLast : 8;
-    constexpr int NSTEP = BODY == BODY_PE ? kHStepsPE : BODY == BODY_HID ? kHStepsHid
+    constexpr int NU = BODY == BODY_LAST ? kHTilesLast : BODY == BODY_HIDSIG ? 9 : BODY == BODY_LAST0 ? 4 : 8;
+    constexpr int NSTEP = BODY == BODY_PE ? kHStepsPE : (BODY == BODY_HID || BODY == BODY_HIDSIG || BODY == BODY_LAST0) ? kHStepsHid
                           : BODY == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
+    constexpr int SIG0 = BODY == BODY_HIDSIG ? 1 : 0;      // tiles before the first hidden tile (the leading sigma tile)
     constexpr int TPS = FAST ? 1 : 2;        // quads (A fragments) per k-step: hi [, lo]
     constexpr int QPU = TPS * NSTEP;
     constexpr int NQ = NU * QPU;
@@ -169,9 +192,9 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
     (void)ycarry;
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        f32x16& acc = accs[u & 3];
-        f32x16& prv = accs[(u + 3) & 3];
-        f32x16& nxt = accs[(u + 1) & 3];
+        f32x16& acc = accs[(u + ROT) & 3];
+        f32x16& prv = accs[(u + ROT + 3) & 3];
+        f32x16& nxt = accs[(u + ROT + 1) & 3];
         if constexpr (u == 0 && !PENDING) load_bias(bias_off_bytes, acc);   // first layer of a tile: exposed once
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
@@ -211,7 +234,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             (void)a_lo;
             frag4 bh_, bl_;
             if constexpr (BODY == BODY_PE) { bh_ = peh[n]; bl_ = pel[n]; }
-            else if constexpr (BODY == BODY_HID) { bh_ = xh[n]; bl_ = xl[n]; }
+            else if constexpr (BODY == BODY_HID || BODY == BODY_HIDSIG || BODY == BODY_LAST0) { bh_ = xh[n]; bl_ = xl[n]; }
             else if constexpr (BODY == BODY_SKIP) {
                 if constexpr (n < kHStepsPE) { bh_ = peh[n]; bl_ = pel[n]; }
                 else { bh_ = xh[n - kHStepsPE]; bl_ = xl[n - kHStepsPE]; }
@@ -224,9 +247,11 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             // all 16 steps (fragment dwords are packed on odd steps); the previous LAYER's tile 7 goes a pair per
             // step over steps 0..7 because its fragments are read from step 14 on.
             constexpr bool kPend = (u == 0) && PENDING && n < 8;
-            constexpr bool kPrevS = (u > 0) && BODY != BODY_PE && NSTEP >= 16 && n < 16;
-            constexpr int et = kPend ? 7 : (u > 0 ? u - 1 : 0);
-            constexpr bool kXc = BODY == BODY_LAST && kPrevS;
+            constexpr bool kPrevS = (u > SIG0) && BODY != BODY_PE && NSTEP >= 16 && n < 16;
+            constexpr int et = kPend ? 7 : (u > SIG0 ? u - 1 - SIG0 : 0);      // hidden-tile index of the previous tile
+            constexpr bool kXc = (BODY == BODY_LAST || BODY == BODY_LAST0) && kPrevS;
+            // the leading sigma tile (row 0 = the raw density, no activation, src/NeRF.py:283) is complete after tile 0
+            if constexpr (BODY == BODY_HIDSIG && u == 1 && n == 0) sigma_raw = prv[0];
             if constexpr (!FAST) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
@@ -259,7 +284,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             // contiguous in the constant region) into the accumulator it will use -- free since 2 tiles
             if constexpr (n == (NSTEP >= 12 ? 10 : 0)) {
                 if constexpr (u + 1 < NU) load_bias(bias_off_bytes + (u + 1) * 128, nxt);
-                else if constexpr (BODY != BODY_LAST) load_bias(bias_off_bytes + 8 * 128, nxt);
+                else if constexpr (BODY != BODY_LAST && BODY != BODY_LAST0) load_bias(bias_off_bytes + NU * 128, nxt);
             }
             // layer 0 has only 3 k-steps per tile: its epilogues go in one block per tile
             if constexpr (BODY == BODY_PE && u > 0 && n == 0) {
@@ -272,12 +297,18 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             }
             // last tile of an in-place layer: fragment m-1 of x-in died with k-step m-1; tiles 0..5 of
             // the new activations (fragments 0..11) are complete by now
-            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && u == NU - 1) {
+            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP || BODY == BODY_HIDSIG) && u == NU - 1) {
                 constexpr int m = BODY == BODY_SKIP ? n - kHStepsPE : n;
                 if constexpr (m >= 1 && m - 1 < 12) { xh[m - 1] = nh[m - 1]; xl[m - 1] = nl[m - 1]; }
             }
         });
     });
+    if constexpr (BODY == BODY_LAST0) {
+        // the last 32 features have no following chain in this body: their activation is exposed once per tile
+        f32x16& lastacc = accs[(NU - 1 + ROT) & 3];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[(NU - 1) * 16 + r] = act(lastacc[r]);
+    }
     if constexpr (BODY == BODY_LAST) {
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
         sigma_raw = accs[(NU - 1) & 3][0];
@@ -305,8 +336,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo
     }
 }
 
-template <bool FAST, bool STASH = false>
+template <bool FAST, bool STASH = false, bool XYZ = false>
 __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
+    static_assert(!(STASH && XYZ), "the xyz-only network trains on the layer-wise path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -319,13 +351,13 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
     const long long ntiles = (a.M + 127) / 128;
     if ((long long)blockIdx.x >= ntiles) return;
 
-    for (int i = tid; i < kHConstFloats / 4; i += 256)
+    for (int i = tid; i < (XYZ ? kXConstFloats : kHConstFloats) / 4; i += 256)
         reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
 
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = FAST ? kFStreamChunks : kHStreamChunks;
+    p.n_chunks = XYZ ? (FAST ? kXFStreamChunks : kXStreamChunks) : (FAST ? kFStreamChunks : kHStreamChunks);
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
@@ -367,7 +399,8 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             dx = d[0]; dy = d[1]; dz = d[2];
         } else {
             px = a.in_a[mm * 3 + 0]; py = a.in_a[mm * 3 + 1]; pz = a.in_a[mm * 3 + 2];
-            dx = a.in_b[mm * 3 + 0]; dy = a.in_b[mm * 3 + 1]; dz = a.in_b[mm * 3 + 2];
+            if constexpr (XYZ) { dx = dy = dz = 0.f; }        // no view directions in this network (may be null)
+            else { dx = a.in_b[mm * 3 + 0]; dy = a.in_b[mm * 3 + 1]; dz = a.in_b[mm * 3 + 2]; }
         }
         const float kPi = 3.1415927410125732f;
         // 24 slots per lane half: h=0: sin of the 15 angles, x, y, z; h=1: cos of the 15 angles
@@ -436,22 +469,27 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
-        st_prev = st_cur;
-        st_cur = st_of(8);
-        mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(8);
-        mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
-        layer_body_h<BODY_LAST, true, FAST, STASH>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
-        STAMP(t1); acc_t[4] += t1 - t0;
-
+        if constexpr (XYZ) {
+            layer_body_h<BODY_HIDSIG, true, FAST, false, 0>(p, lane16, cb_h, kXConstBiasSig * 4, a.alpha, nullptr, nullptr, nullptr, nullptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            layer_body_h<BODY_LAST0, true, FAST, false, 1>(p, lane16, cb_h, kXConstBias9 * 4, a.alpha, nullptr, nullptr, nullptr, nullptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+        } else {
+            st_prev = st_cur;
+            st_cur = st_of(8);
+            mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(8);
+            mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
+            layer_body_h<BODY_LAST, true, FAST, STASH>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            STAMP(t1); acc_t[4] += t1 - t0;
+        }
         // rgb head (128 -> 3) on the VALU in fp32
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 w0 = lds_read4(cb_h + (kHConstWrgb + 0 * 128 + t * 32 + g * 8) * 4);
-                const f32x4 w1 = lds_read4(cb_h + (kHConstWrgb + 1 * 128 + t * 32 + g * 8) * 4);
-                const f32x4 w2 = lds_read4(cb_h + (kHConstWrgb + 2 * 128 + t * 32 + g * 8) * 4);
+                constexpr int kW = XYZ ? kXConstWrgb : kHConstWrgb;
+                const f32x4 w0 = lds_read4(cb_h + (kW + 0 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w1 = lds_read4(cb_h + (kW + 1 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w2 = lds_read4(cb_h + (kW + 2 * 128 + t * 32 + g * 8) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = xc[t * 16 + g * 4 + e];
@@ -464,7 +502,7 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
         o0 += __shfl_xor(o0, 32);
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
-        const f32x4 bh = lds_read4(kLdsConst + kHConstBHead * 4);
+        const f32x4 bh = lds_read4(kLdsConst + (XYZ ? kXConstBHead : kHConstBHead) * 4);
         if (valid && h == 0) {
             f32x4 out;
             out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = sigma_raw;
@@ -485,6 +523,8 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) { mlp_f16_body<false>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16_kernel(const MlpArgs a) { mlp_f16_body<true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_stash_kernel(const MlpArgs a) { mlp_f16_body<false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16x3_xyz_kernel(const MlpArgs a) { mlp_f16_body<false, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16_xyz_kernel(const MlpArgs a) { mlp_f16_body<true, false, true>(a); }
 
 void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream) {
     if (a.M <= 0) return;
@@ -493,10 +533,15 @@ void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream) {
     hipLaunchKernelGGL(mlp_f16x3_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
-void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass) {
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass, bool xyz_only) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 127) / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    if (xyz_only) {
+        if (single_pass) hipLaunchKernelGGL(mlp_f16_xyz_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+        else hipLaunchKernelGGL(mlp_f16x3_xyz_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+        return;
+    }
     if (single_pass) hipLaunchKernelGGL(mlp_f16_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
     else hipLaunchKernelGGL(mlp_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
@@ -514,6 +559,10 @@ void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_stash_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_xyz_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_xyz_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
@@ -575,19 +624,24 @@ struct HLayer { const float* k; const float* b; int in, out; };
 template <class EmitW, class EmitC>
 static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c) {
     const int kd = 256 + 8 * (n_angles + 1);
-    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
-                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
-    struct Lay { long long k, b; int in, out; } L[11];
+    const bool xyz_only = n_angles == 0;
+    // Keras creation order; xyz-only (src/NeRF.py:248-288): ..., 8: 256 -> 256, 9: 256 -> 128, 10: 128 -> 3, 11: 256 -> 1
+    const int shapes_dir[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}, {0, 0}};
+    const int shapes_xyz[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {256, 256}, {256, 128}, {128, 3}, {256, 1}};
+    const int (*shapes)[2] = xyz_only ? shapes_xyz : shapes_dir;
+    struct Lay { long long k, b; int in, out; } L[12];
     long long off = 0;
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < (xyz_only ? 12 : 11); ++i) {
         L[i].in = shapes[i][0]; L[i].out = shapes[i][1];
         L[i].k = off; off += (long long)L[i].in * L[i].out;
         L[i].b = off; off += L[i].out;
     }
     size_t chunk = 0;
     auto emit_body = [&](int layer, int body) {
-        const int NU = body == BODY_LAST ? kHTilesLast : 8;
-        const int NSTEP = body == BODY_PE ? kHStepsPE : body == BODY_HID ? kHStepsHid
+        const int NU = body == BODY_LAST ? kHTilesLast : body == BODY_HIDSIG ? 9 : body == BODY_LAST0 ? 4 : 8;
+        const int NSTEP = body == BODY_PE ? kHStepsPE : (body == BODY_HID || body == BODY_HIDSIG || body == BODY_LAST0) ? kHStepsHid
                           : body == BODY_SKIP ? kHStepsPE + kHStepsHid : kHStepsHid + kHStepsDir;
         const long long b0 = (long long)chunk * (kHChunkBytes / 2);
         for (int u = 0; u < NU; ++u)
@@ -597,7 +651,7 @@ static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c)
                         const int i = lane & 31, h = lane >> 5;
                         int row;
                         if (body == BODY_PE) row = h_pe_row(n * 8 + e, h);
-                        else if (body == BODY_HID) row = h_hid_row(n, e, h);
+                        else if (body == BODY_HID || body == BODY_HIDSIG || body == BODY_LAST0) row = h_hid_row(n, e, h);
                         else if (body == BODY_SKIP) {
                             if (n < kHStepsPE) row = h_pe_row(n * 8 + e, h);
                             else row = kXyzDim + h_hid_row(n - kHStepsPE, e, h);
@@ -608,6 +662,8 @@ static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c)
                         long long src = -1;
                         if (row >= 0) {
                             if (body == BODY_LAST && u == kHTilesLast - 1) src = i == 0 ? L[10].k + row : -1;   // sigma row
+                            else if (body == BODY_HIDSIG && u == 0) src = i == 0 ? L[11].k + row : -1;           // leading sigma row
+                            else if (body == BODY_HIDSIG) src = L[layer].k + (long long)row * L[layer].out + 32 * (u - 1) + i;
                             else src = L[layer].k + (long long)row * L[layer].out + 32 * u + i;
                         }
                         if (hi_only) {
@@ -623,9 +679,20 @@ static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c)
     for (int l = 1; l <= 3; ++l) emit_body(l, BODY_HID);
     emit_body(4, BODY_SKIP);
     for (int l = 5; l <= 7; ++l) emit_body(l, BODY_HID);
-    emit_body(8, BODY_LAST);
     for (int l = 0; l < 8; ++l)
         for (int f = 0; f < 256; ++f) emit_c(kHConstBias + l * 256 + f, L[l].b + f);
+    if (xyz_only) {
+        emit_body(8, BODY_HIDSIG);
+        emit_body(9, BODY_LAST0);
+        emit_c(kXConstBiasSig + 0, L[11].b);
+        for (int f = 0; f < 256; ++f) emit_c(kXConstBias8 + f, L[8].b + f);
+        for (int f = 0; f < 128; ++f) emit_c(kXConstBias9 + f, L[9].b + f);
+        for (int c = 0; c < 3; ++c)
+            for (int f = 0; f < 128; ++f) emit_c(kXConstWrgb + c * 128 + f, L[10].k + f * 3 + c);
+        for (int c = 0; c < 3; ++c) emit_c(kXConstBHead + c, L[10].b + c);
+        return;
+    }
+    emit_body(8, BODY_LAST);
     for (int f = 0; f < 128; ++f) emit_c(kHConstBias8 + f, L[8].b + f);
     emit_c(kHConstBiasSig + 0, L[10].b);
     for (int c = 0; c < 3; ++c)
@@ -634,7 +701,8 @@ static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c)
 }
 
 static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_out, float* const_out, bool hi_only) {
-    memset(stream_out, 0, hi_only ? kStreamBytesF16Hi : kStreamBytesF16);
+    memset(stream_out, 0, n_angles == 0 ? (hi_only ? kStreamBytesF16HiXyz : kStreamBytesF16Xyz)
+                                        : (hi_only ? kStreamBytesF16Hi : kStreamBytesF16));
     memset(const_out, 0, kConstBytes);
     uint16_t* base = reinterpret_cast<uint16_t*>(stream_out);
     pack_f16_map(n_angles, hi_only,

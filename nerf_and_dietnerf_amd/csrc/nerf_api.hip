@@ -59,7 +59,20 @@ int enter(nerf_ctx* c) {
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob) {
     HIP_OK(hipSetDevice(c->cfg.device));
     NetWeights& n = c->net[which];
-    if (c->cfg.n_angles == 0) {      // xyz-only network: served by the layer-wise path (train_api.hip), nothing to pack
+    if (c->cfg.n_angles == 0) {
+        // xyz-only network: the exact-fp32 mode is served by the layer-wise path (train_api.hip: nothing to pack for it);
+        // the two fp16-core modes run on the fused kernels' xyz-only variant with their own streams
+        std::vector<uint16_t> sx(kStreamBytesF16Xyz / 2), sx1(kStreamBytesF16HiXyz / 2);
+        std::vector<float> cx(kConstFloats);
+        pack_weights_f16x3(blob, 0, sx.data(), cx.data());
+        pack_weights_f16(blob, 0, sx1.data(), cx.data());
+        if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16Xyz));
+        if (!n.stream_h1) HIP_OK(hipMalloc((void**)&n.stream_h1, kStreamBytesF16HiXyz));
+        if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipMemcpy(n.stream_h, sx.data(), kStreamBytesF16Xyz, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(n.stream_h1, sx1.data(), kStreamBytesF16HiXyz, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(n.cst_h, cx.data(), kConstBytes, hipMemcpyHostToDevice));
         const size_t nf0 = nerf_blob_size(&c->cfg);
         if (n.host_blob.data() != blob) n.host_blob.assign(blob, blob + nf0);
         n.loaded = true;
@@ -98,8 +111,6 @@ int check_cfg(const nerf_config* cfg) {
     if (!cfg) return fail("nerf_config is NULL");
     if (cfg->n_angles != 2 && cfg->n_angles != 1 && cfg->n_angles != 0)
         return fail("n_angles_for_model should be 1 or 2.");   // message of src/UtilsCV.py:138 (0 = xyz-only network)
-    if (cfg->n_angles == 0 && cfg->precision != NERF_PRECISION_FP32)
-        return fail("the xyz-only network (n_angles_for_model=0) runs on the layer-wise fp32 path: use NERF_PRECISION_FP32");
     if (cfg->n_pos_enc_xyz != kLx || cfg->n_pos_enc_dir != kLd || cfg->hidden_dim != kHidden ||
         cfg->last_hidden_dim != kLast)
         return fail("fused kernel is specialised for Lx=%d Ld=%d hidden=%d last=%d (got %d %d %d %d)", kLx, kLd,
@@ -116,7 +127,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
             int S, int mode) {
     if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
     if (int r = train_flush_weights(c, which)) return r;   // re-pack the operand streams after optimizer steps
-    if (c->cfg.n_angles == 0) {
+    if (c->cfg.n_angles == 0 && c->cfg.precision == NERF_PRECISION_FP32) {
         if (mode == 1 && !in_a) return fail("NULL argument");
         c->timed_rows += c->timing ? M : 0;
         return layerwise_forward(c, which, in_a, in_b, z, raw, M, S, mode);
@@ -142,7 +153,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         c->timed_rows += M;
         HIP_OK(hipEventRecord(e0, c->stream));
     }
-    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16);
+    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16, c->cfg.n_angles == 0);
     else launch_mlp_fp32(a, c->num_cus, c->stream);
     if (c->timing) HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipGetLastError());
@@ -320,8 +331,6 @@ int nerf_ctx_set_precision(nerf_ctx* c, int precision) {
     if (!c) return fail("ctx is NULL");
     if (precision != NERF_PRECISION_FP32 && precision != NERF_PRECISION_F16X3 && precision != NERF_PRECISION_F16)
         return fail("unknown precision %d", precision);
-    if (c->cfg.n_angles == 0 && precision != NERF_PRECISION_FP32)
-        return fail("the xyz-only network (n_angles_for_model=0) runs on the layer-wise fp32 path: use NERF_PRECISION_FP32");
     HIP_OK(hipStreamSynchronize(c->stream));
     c->cfg.precision = precision;
     return 0;

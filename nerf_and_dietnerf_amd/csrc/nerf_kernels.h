@@ -38,6 +38,8 @@ constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kCh
 constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
 constexpr size_t kStreamBytesF16 = size_t(66) * 32 * kQuadBytes;   // f16x3 stream: 66 chunks of 32 KiB (mlp_f16x3.hip)
 constexpr size_t kStreamBytesF16Hi = size_t(33) * 32 * kQuadBytes; // single-pass fp16 stream: hi fragments only
+constexpr size_t kStreamBytesF16Xyz = size_t(73) * 32 * kQuadBytes;    // the xyz-only network's streams (12 Dense layers)
+constexpr size_t kStreamBytesF16HiXyz = size_t(37) * 32 * kQuadBytes;
 
 // ---- constant region (biases + head weights), floats ----
 constexpr int kConstBias = 0;                       // 8 x 256 hidden-layer biases (layers 0..7)
@@ -46,7 +48,7 @@ constexpr int kConstWrgb = 2176;                    // [3][128]
 constexpr int kConstBHead = 2560;                   // b_r, b_g, b_b, b_sigma
 constexpr int kConstWsigH = 2564;                   // [256]  sigma head, hidden part
 constexpr int kConstWsigD = 2820;                   // [3][2][4] sigma head, dir part (g, half, e)
-constexpr int kConstFloats = 2848;                  // padded to a multiple of 16 B
+constexpr int kConstFloats = 2880;                  // the LDS carve of the constants (largest user: the xyz-only f16 variant)
 constexpr int kConstBytes = kConstFloats * 4;
 
 // LDS carve of the MLP kernel
@@ -82,15 +84,17 @@ void mlp_fp32_set_attributes();
 void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
 
 // mlp_f16x3.hip
-void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);   // single_pass: hi*hi only
+// single_pass: hi*hi only; xyz_only: the 12-layer network without view directions (its own streams / constants)
+void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false, bool xyz_only = false);
 void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream);   // 3-pass forward that also writes a.st_ptr
 // device-side re-pack of the 3-pass stream + constants from a blob (tables from build_f16x3_gather, host)
 void build_f16x3_gather(int n_angles, int32_t* stream_idx /*kStreamBytesF16/2*/, int32_t* const_idx /*kConstFloats*/);
 void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
                          hipStream_t s);
 void mlp_f16x3_set_attributes();
-void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16*/, float* const_out /*kConstFloats*/);
-void pack_weights_f16(const float* blob, int n_angles, void* stream_out /*kStreamBytesF16Hi*/, float* const_out /*kConstFloats*/);
+// stream_out: kStreamBytesF16 / kStreamBytesF16Hi bytes (kStreamBytesF16Xyz / kStreamBytesF16HiXyz when n_angles == 0)
+void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
+void pack_weights_f16(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
 
 // mlp_bwd_f16x3.hip -- the trainer's fused data-gradient chain (the stash forward's counterpart)
 constexpr size_t kBwdStreamBytes = size_t(65) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles

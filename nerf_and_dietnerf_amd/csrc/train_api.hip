@@ -598,10 +598,8 @@ int layerwise_forward(nerf_ctx* c, int which, const float* in_a, const float* in
 int train_flush_weights(nerf_ctx* c, int which) {
     TrainState* t = c->train;
     if (!t || !t->net[which].present || !t->net[which].render_dirty) return 0;
-    if (c->cfg.n_angles == 0) {      // the layer-wise path reads the trainer's own matrices: nothing to re-pack
-        t->net[which].render_dirty = false;
-        return 0;
-    }
+    // (the xyz-only network's exact-fp32 render mode reads the trainer's own matrices, its fp16-core modes the streams
+    // re-packed here like everyone else's)
     NetWeights& nw = c->net[which];
     HIP_OK(hipMemcpyAsync(nw.host_blob.data(), t->net[which].blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost,
                           c->stream));

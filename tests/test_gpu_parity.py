@@ -590,13 +590,16 @@ def test_nonfinite_watch(golden_ckpt, golden_vec):
     ctx.close()
 
 
-def test_xyz_only_network(oracle):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+def test_xyz_only_network(oracle, precision):
     """n_angles_for_model == 0 (get_network_only_xyz, src/NeRF.py:248-288; 5 of the reference's configs): 12 Dense
-    layers, sigma from the 8th hidden layer, no direction input.  Served by the layer-wise fp32 MFMA GEMM path
-    (no fused kernel is built for this network): model_predict, render_rays and the two-pass render vs the oracle."""
+    layers, sigma from the 8th hidden layer, no direction input.  The exact-fp32 mode is served by the layer-wise fp32
+    MFMA GEMM path, the two fp16-core modes by the fused kernel's xyz-only variant (sigma as a leading 9th tile of the
+    extra hidden layer, then a 256 -> 128 body without direction k-steps): model_predict, render_rays and the two-pass
+    render vs the oracle -- fp32-class bars for fp32 / f16x3, fp16-class bars for the single-pass mode."""
     import nerf_and_dietnerf_amd as N
     near, far = 0.5, 2.5
-    ctx = N.Context(n_angles=0, near=near, far=far)
+    ctx = N.Context(n_angles=0, near=near, far=far, precision=precision)
     bc, bf = N.glorot_blob(5, n_angles=0), N.glorot_blob(6, n_angles=0)
     bc[-1] = bf[-1] = 1.5                                   # lift sigma so that the compositing is not trivial
     ctx.load_weights(0, bc)
@@ -611,15 +614,44 @@ def test_xyz_only_network(oracle):
     xyz = rng.standard_normal((1000, 3)).astype(np.float32)
     raw = ctx.model_predict(0, xyz, None)
     ref_raw = oracle.model_predict(coarse, xyz, None)
-    assert np.abs(raw - ref_raw).max() <= 2e-5 * max(1.0, np.abs(ref_raw).max())
+    raw_tol, rgb_tol, z_tol = (2e-5, RGB_TOL, 2e-5) if precision != "f16" else (5e-2, 3e-2, None)
+    assert np.abs(raw - ref_raw).max() <= raw_tol * max(1.0, np.abs(ref_raw).max())
     out = ctx.render(o, d, sc, sf, uc, uf)
     ref = oracle.render(coarse, fine, o, d, near, far, uc, uf, n_angles=0)
-    assert np.abs(out[0] - ref[0]).max() <= RGB_TOL
-    assert np.abs(out[5] - ref[5]).max() <= 2e-5             # depths: the sampler sees weights that differ by ulps
-    assert np.abs(out[1] - ref[1]).max() <= 2e-5
-    with pytest.raises(RuntimeError, match="layer-wise fp32 path"):
-        ctx.set_precision("f16x3")
+    assert np.abs(out[0] - ref[0]).max() <= rgb_tol
+    if z_tol is not None:
+        assert np.abs(out[5] - ref[5]).max() <= z_tol        # depths: the sampler sees weights that differ by ulps
+        assert np.abs(out[1] - ref[1]).max() <= z_tol
+    assert ctx.read_nonfinite() == 0
     ctx.close()
+
+
+def test_xyz_only_network_rate(capsys):
+    """The fused xyz-only variant must not be a second-class path: >= 0.8 of the view-direction network's rate at
+    256x256, 64 + 128 (it does 262144 more MACs per sample row: one 256x256 layer instead of the 24 direction rows)."""
+    import time
+    import torch
+    import nerf_and_dietnerf_amd as N
+    rates = {}
+    for n_angles in (2, 0):
+        ctx = N.Context(n_angles=n_angles, near=0.5, far=2.5, precision="f16x3")
+        ctx.load_weights(0, N.glorot_blob(1, n_angles=n_angles))
+        ctx.load_weights(1, N.glorot_blob(2, n_angles=n_angles))
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[2, 3] = 1.5
+        f = lambda s: ctx.render_image(c2w, 0.6, 256, 256, 1 << 18, 64, 128, seed=s, device_out=True, rgb_only=True)  # noqa: E731
+        f(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(5):
+            f(s + 1)
+        torch.cuda.synchronize()
+        rates[n_angles] = 5 * 65536 / (time.perf_counter() - t0)
+        ctx.close()
+    with capsys.disabled():
+        print(f"\n[xyz-only fused kernel] {rates[0]:.3e} rays/s vs {rates[2]:.3e} rays/s with view directions "
+              f"(ratio {rates[0] / rates[2]:.2f})")
+    assert rates[0] >= 0.8 * rates[2]
 
 
 def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):

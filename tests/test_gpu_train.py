@@ -444,6 +444,30 @@ def test_train_step_with_one_rank_communicator(oracle, golden_ckpt):
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("alpha", [1.0, 0.05])
+def test_gradients_at_the_reference_sample_counts(oracle, golden_ckpt, alpha, capsys):
+    """The float64 autograd oracle at the reference's own sample counts (64 coarse + 128 fine) on a 32-ray batch, sampler
+    term on: pins sample_pdf_bwd and the backward chain's per-sample scaling at S = 64 / 128 (the small problems above
+    use 16 + 24 samples).  alpha = 1 removes the LeakyReLU sign-flip excuse altogether: bar 2e-4 of max|g| for both
+    networks; with the reference's alpha = 0.05 the flip-limited bars of test_gradients_coarse_and_fine apply."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt, n=32, sc=64, sf=128, seed=5)
+    ctx = _ctx(p, leaky_relu_alpha=alpha)
+    ctx.train_begin(5e-4, sampler_gradient=True)
+    m, gc, gf = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
+                          sampler_grad=True, alpha=alpha)
+    ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
+    cc, cf = _cos(gc, r["grad_coarse"]), _cos(gf, r["grad_fine"])
+    with capsys.disabled():
+        print(f"\n[32 rays x (64 + 128), alpha {alpha}, sampler term on] vs float64 autograd: max gradient difference / "
+              f"max|g| coarse {ec:.2e}, fine {ef:.2e}; cosine {cc:.7f}, {cf:.7f}")
+    assert abs(m["loss"] - r["loss"]) <= 2e-6 * r["loss"]
+    tol, cos_min = (2e-4, 0.9999999) if alpha == 1.0 else (5e-2, 0.999)
+    assert ec <= tol and cc > cos_min and ef <= tol and cf > cos_min
+    ctx.close()
+
+
 def test_fp16_core_trainer_equals_exact_fp32_trainer_at_full_size(oracle, golden_ckpt, capsys, monkeypatch):
     """The default trainer forms every product on the fp16 matrix cores with split operands; the exact-fp32 MFMA path
     stays behind NERF_TRAIN_FORWARD / NERF_TRAIN_WGRAD / NERF_TRAIN_DGRAD.  On a batch far too large for the CPU oracle
