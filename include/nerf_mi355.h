@@ -188,6 +188,19 @@ int nerf_train_gradients(nerf_ctx* ctx, const float* rays_orig, const float* ray
                          int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine,
                          uint64_t seed, float* grad_coarse, float* grad_fine, float* metrics, int mem);
 int nerf_train_apply(nerf_ctx* ctx, const float* grad_coarse, const float* grad_fine, int mem);
+/* Backward through NeRF.render() itself (src/NeRF.py:109-134): the graph DietNeRF's consistency loss differentiates
+ * when it renders an image under the tape (src/DietNeRF.py:204-222, render_image -> render per ray batch).  Unlike
+ * train_step, the fine pass runs on sort(concat(z_fine, z_coarse)) (Sc + Sf samples) and only its rgb is an output.
+ * d_rgb (N,3) = dL/d(render()[0]) supplied by the caller (e.g. from its embedding network); the call re-runs the
+ * forward with activation stash on these N rays -- same draws as nerf_render with the same (seed, ray_base) -- and
+ * leaves dL/d(weights) in the ctx's gradient blobs: overwriting them (accumulate = 0) or adding to what
+ * nerf_train_gradients left there (accumulate = 1: the reference sums both losses before one Adam step), ready for
+ * nerf_train_apply(ctx, NULL, NULL, mem).  The coarse network receives gradient only through the inverse-CDF sampler
+ * (none with sampler_gradient = 0).  rgb_out / grad_coarse / grad_fine: optional copies. */
+int nerf_train_render_gradients(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* d_rgb,
+                                int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine,
+                                uint64_t seed, int64_t ray_base, int32_t accumulate, float* rgb_out,
+                                float* grad_coarse, float* grad_fine, int mem);
 /* Current weights of a network as a blob (model.get_weights(), src/UtilsFiles.py:153-164 saves these). */
 int nerf_get_weights(nerf_ctx* ctx, int which, float* blob, size_t n_floats, int mem);
 

@@ -71,6 +71,8 @@ SYMBOLS = [
     ("nerf_train_step", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, C.c_int]),
     ("nerf_train_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, _P, _P, C.c_int]),
     ("nerf_train_apply", C.c_int, [_P, _P, _P, C.c_int]),
+    ("nerf_train_render_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, _I32, _P, _P, _P,
+                                              C.c_int]),
     ("nerf_get_weights", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_ctx_enable_timing", C.c_int, [_P, C.c_int]),
     ("nerf_ctx_read_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),

@@ -58,6 +58,8 @@ struct TrainState {
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
+    bool acc_grads = false;         // the running backward pass ADDS to the gradient blobs (nerf_train_render_gradients)
+    DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
@@ -286,6 +288,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     r.partial = g.partial; r.Kp = L.Kp; r.Nw = Ncols; r.splits = (int)((Mp + rps - 1) / rps);
     r.grad_w = n.grad + L.w_off; r.grad_b = n.grad + L.b_off;
     r.K_real = L.K_real; r.N_real = L.N_real; r.n_src_off = n_src_off; r.rowmap = L.rowmap;
+    r.accumulate = t->acc_grads ? 1 : 0;
     launch_reduce_grad(r, c->stream);
 }
 
@@ -486,6 +489,100 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     return 0;
 }
 
+// Backward through NeRF.render() itself (src/NeRF.py:109-134), the graph DietNeRF's consistency loss differentiates
+// (src/DietNeRF.py:204-222): coarse pass -> inverse-CDF samples -> fine pass on sort(concat(z_new, z_coarse)) -> rgb.
+// Given d_rgb = dL/d(render()[0]) it leaves dL/d(weights) of both networks in (or adds it to) the gradient blobs:
+// the fine network through its Sc+Sf merged samples, the coarse network only through the sampler (its own rgb is
+// not an output of render() when a fine network exists).
+int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const float* d_rgb_in, int64_t N, int Sc,
+                          int Sf, const float* u_c, const float* u_f, uint64_t seed, int64_t ray_base, bool accumulate,
+                          int mem) {
+    TrainState* t = c->train;
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
+    if (!rays_o || !rays_d || !d_rgb_in) return fail("NULL argument");
+    if (N <= 0) return fail("need at least one ray (got %lld)", (long long)N);
+    if (Sc < 1 || Sc > 1024) return fail("bad coarse sample count %d", Sc);
+    const bool fine = Sf > 0 && t->net[1].present;
+    if (fine && Sc < 2) return fail("hierarchical sampling needs at least 2 coarse samples (got %d)", Sc);
+    if (fine && Sf > 256) return fail("training supports at most 256 fine samples per ray (got %d)", Sf);
+    if (fine && (sample_pdf_lds_bytes(Sc, Sf) > 64 * 1024 || sample_pdf_bwd_lds_bytes(Sc, Sf) > 64 * 1024))
+        return fail("Sc=%d Sf=%d exceeds the sampler's LDS budget", Sc, Sf);
+    const size_t f = sizeof(float);
+    const float *o, *d, *dr, *uc, *uf;
+    if (int r = stage_in(c, t->o, rays_o, N * 4 * f, mem, &o)) return r;
+    if (int r = stage_in(c, t->d, rays_d, N * 4 * f, mem, &d)) return r;
+    if (int r = stage_in(c, t->tgt, d_rgb_in, N * 3 * f, mem, &dr)) return r;
+    if (int r = stage_in(c, t->u_c, u_c, (size_t)N * Sc * f, mem, &uc)) return r;
+    if (int r = stage_in(c, t->u_f, fine ? u_f : nullptr, (size_t)N * (fine ? Sf : 0) * f, mem, &uf)) return r;
+    const int Sm = Sc + Sf;                                          // the fine pass renders the merged samples
+    PassDims dc{N, Sc, N * Sc, (N * Sc + 127) / 128 * 128};
+    PassDims df{N, Sm, N * (long long)Sm, (N * (long long)Sm + 127) / 128 * 128};
+    const long long Mmax = fine ? df.Mp : dc.Mp;
+    int r = ensure_pass(c, t->pass[0], dc);
+    if (fine) r |= ensure_pass(c, t->pass[1], df);
+    r |= ensure(c, t->Ga, Mmax * 256 * f);
+    r |= ensure(c, t->Gb, Mmax * 256 * f);
+    r |= ensure(c, t->G9, Mmax * 128 * f);
+    r |= ensure(c, t->Graw, Mmax * 4 * f);
+    r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
+    r |= ensure(c, t->partial, (size_t)kTrainSplitsWide * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->d_wext, dc.M * f);
+    r |= ensure(c, t->d_zf, (fine ? N * (long long)Sf : 1) * f);
+    r |= ensure(c, t->z_new, (fine ? N * (long long)Sf : 1) * f);
+    r |= ensure(c, t->d_zm, (fine ? df.M : 1) * f);
+    r |= ensure(c, t->zero_rgb, N * 3 * f);
+    r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
+    if (r) return r;
+    float* Graw = (float*)t->Graw.p;
+    t->acc_grads = accumulate;
+
+    TPass& pc = t->pass[0];
+    launch_z_values(c->cfg.near_boundary, c->cfg.far_boundary, N, Sc, uc, seed, ray_base, (float*)pc.z.p, c->stream);
+    if (int q = forward_pass(c, t, 0, dc, o, d)) { t->acc_grads = false; return q; }
+    const bool through_sampler = fine && t->cfg.sampler_gradient != 0;
+    int q = 0;
+    if (fine) {
+        TPass& pf = t->pass[1];
+        launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, ray_base, (float*)t->z_new.p,
+                          (float*)pf.z.p, c->stream);                // z_new (sorted) and the merged, sorted depths
+        q = forward_pass(c, t, 1, df, o, d);
+        if (!q) {
+            HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
+            float* d_zm = through_sampler ? (float*)t->d_zm.p : nullptr;
+            launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sm, dr, nullptr,
+                                 Graw, d_zm, c->stream);
+            q = backward_pass(c, t, 1, df, o, d, d_zm);
+            if (!q && through_sampler) {
+                launch_unmerge_grad((const float*)t->z_new.p, (const float*)pc.z.p, d_zm, N, Sc, Sf, (float*)t->d_zf.p,
+                                    c->stream);
+                launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, ray_base,
+                                      (const float*)t->d_zf.p, (float*)t->d_wext.p, c->stream);
+            }
+        }
+        if (!q) {
+            if (through_sampler) {
+                // the coarse network: no direct rgb term, only dL/d(weights_coarse) from the sampler
+                HIP_OK(hipMemsetAsync(t->zero_rgb.p, 0, N * 3 * f, c->stream));
+                HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
+                launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc,
+                                     (const float*)t->zero_rgb.p, (const float*)t->d_wext.p, Graw, nullptr, c->stream);
+                q = backward_pass(c, t, 0, dc, o, d, nullptr);
+            } else if (!accumulate) {
+                HIP_OK(hipMemsetAsync(t->net[0].grad, 0, t->nblob * f, c->stream));   // render() does not depend on it
+            }
+        }
+    } else {
+        HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
+        launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, dr, nullptr, Graw,
+                             nullptr, c->stream);
+        q = backward_pass(c, t, 0, dc, o, d, nullptr);
+    }
+    t->acc_grads = false;
+    if (q) return q;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int read_metrics(nerf_ctx* c, bool fine, float* metrics) {
     if (!metrics) return 0;
     float h[2] = {0.f, 0.f};
@@ -544,7 +641,7 @@ void train_free(nerf_ctx* c) {
         for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
-                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax};
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb};
     for (DevBuf* b : bs) free_buf(*b);
     delete t;
     c->train = nullptr;
@@ -695,6 +792,26 @@ int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_
     }
     if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
     return read_metrics(c, fine, metrics);
+}
+
+int nerf_train_render_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_dirs, const float* d_rgb, int64_t N,
+                                int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
+                                int64_t ray_base, int32_t accumulate, float* rgb_out, float* grad_coarse,
+                                float* grad_fine, int mem) {
+    ENTER(c);
+    if (int r = render_gradients_impl(c, rays_orig, rays_dirs, d_rgb, N, Sc, Sf, u_coarse, u_fine, seed, ray_base,
+                                      accumulate != 0, mem)) return r;
+    TrainState* t = c->train;
+    const bool fine = Sf > 0 && t->net[1].present;
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (rgb_out) HIP_OK(hipMemcpyAsync(rgb_out, t->pass[fine ? 1 : 0].rgb.p, N * 3 * sizeof(float), kind, c->stream));
+    if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
+    if (grad_fine) {
+        if (!fine) return fail("grad_fine requested but no fine pass ran (Sf = %d)", Sf);
+        HIP_OK(hipMemcpyAsync(grad_fine, t->net[1].grad, t->nblob * sizeof(float), kind, c->stream));
+    }
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int nerf_train_apply(nerf_ctx* c, const float* grad_coarse, const float* grad_fine, int mem) {

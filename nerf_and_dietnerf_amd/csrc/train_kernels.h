@@ -60,6 +60,7 @@ struct ReduceArgs {
     float* grad_w; float* grad_b;       // destinations inside the gradient blob
     int K_real, N_real; int n_src_off;  // gradient column n comes from partial column n_src_off + n
     int rowmap;                         // 0: identity; 1: layer 4 (blob rows [xyz(33); hidden(256)] <- training rows [hidden; xyz])
+    int accumulate;                     // 1: add to the gradient blob instead of overwriting it
 };
 void launch_reduce_grad(const ReduceArgs& a, hipStream_t s);
 
@@ -81,6 +82,8 @@ void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, 
                      long long M, float alpha, float* G9, unsigned* gmax, hipStream_t s);
 void launch_pe_bwd(const float* dA0, const float* dA0b /* added to dA0, or null */, const float* o, const float* d,
                    const float* z, long long N, int S, float* d_z, hipStream_t s);
+void launch_unmerge_grad(const float* z_new, const float* z_c, const float* d_zm, long long N, int S, int Sf, float* d_zf,
+                         hipStream_t s);
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
                            uint64_t seed, long long ray_base, const float* d_zf, float* d_w, hipStream_t s);
 size_t sample_pdf_bwd_lds_bytes(int S, int Sf);

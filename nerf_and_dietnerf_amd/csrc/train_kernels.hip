@@ -769,8 +769,8 @@ __global__ void reduce_grad_kernel(const ReduceArgs a) {
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
     if (live && q == 0) {
-        if (is_bias) a.grad_b[n] = s;
-        else a.grad_w[(size_t)kb * a.N_real + n] = s;
+        float* dst = is_bias ? a.grad_b + n : a.grad_w + (size_t)kb * a.N_real + n;
+        *dst = a.accumulate ? *dst + s : s;
     }
 }
 
@@ -1049,6 +1049,32 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
         acc += dp * dv[c];
     }
     d_z[m] += acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of z = sort(concat(z_new, z_coarse)) (src/NeRF.py:132) w.r.t. z_new: sample_pdf_kernel (aux_kernels.hip)
+// puts the k-th new depth (they are sorted) into slot k + #{coarse depths < it}; the gradient of that slot is its.
+// ------------------------------------------------------------------------------------------------
+__global__ void unmerge_grad_kernel(const float* __restrict__ z_new, const float* __restrict__ z_c,
+                                    const float* __restrict__ d_zm, long long N, int S, int Sf,
+                                    float* __restrict__ d_zf) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Sf) return;
+    const long long ray = i / Sf;
+    const int k = (int)(i % Sf);
+    const float v = z_new[i];
+    const float* zc = z_c + ray * S;
+    int lo = 0, hi = S;                       // # coarse depths < v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] < v) lo = mid + 1; else hi = mid; }
+    d_zf[i] = d_zm[ray * (S + Sf) + k + lo];
+}
+
+void launch_unmerge_grad(const float* z_new, const float* z_c, const float* d_zm, long long N, int S, int Sf, float* d_zf,
+                         hipStream_t s) {
+    const long long n = N * Sf;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(unmerge_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z_new, z_c, d_zm, N, S, Sf,
+                       d_zf);
 }
 
 void launch_pe_bwd(const float* dA0, const float* dA0b, const float* o, const float* d, const float* z, long long N, int S,

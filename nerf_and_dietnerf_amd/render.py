@@ -237,6 +237,21 @@ class Context:
                                                  C.cast(m, C.c_void_p), arr.mem))
         return _metrics(m, fine), gc, gf
 
+    def train_render_gradients(self, rays_orig, rays_dirs, d_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0,
+                               ray_base=0, accumulate=False):
+        """Backward through ``NeRF.render`` (src/NeRF.py:109-134; what DietNeRF's consistency loss differentiates,
+        src/DietNeRF.py:204-222): ``d_rgb`` (N,3) = dL/d(render(...)[0]) -> (rgb (N,3) of the re-run forward,
+        grad_coarse blob, grad_fine blob | None).  ``accumulate=True`` adds to the gradients the last
+        ``train_gradients`` left in the context (then ``train_apply()`` steps on the sum)."""
+        arr, n, (po, pd, pg), uc, uf = self._train_inputs(rays_orig, rays_dirs, d_rgb, n_c, n_f, u_coarse, u_fine)
+        fine = n_f > 0 and self.loaded[1]
+        rgb, prgb = arr.out((n, 3))
+        gc, pgc = arr.out((self.blob_size(),))
+        gf, pgf = arr.out((self.blob_size(),)) if fine else (None, None)
+        _lib.check(self.lib.nerf_train_render_gradients(self.h, po, pd, pg, n, n_c, n_f, uc, uf, seed, ray_base,
+                                                        1 if accumulate else 0, prgb, pgc, pgf, arr.mem))
+        return rgb, gc, gf
+
     def train_apply(self, grad_coarse=None, grad_fine=None) -> None:
         """Adam update from the given gradient blobs (e.g. after an all-reduce), or from the ctx's own."""
         arr = self._arrays(grad_coarse, grad_fine)

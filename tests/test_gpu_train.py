@@ -444,6 +444,46 @@ def test_train_step_with_one_rank_communicator(oracle, golden_ckpt):
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("sampler_gradient", [True, False])
+def test_backward_through_render(oracle, golden_ckpt, sampler_gradient, capsys):
+    """nerf_train_render_gradients: the backward of NeRF.render itself (src/NeRF.py:109-134) -- fine pass on the merged,
+    sorted Sc + Sf samples, gradient through sort(concat) and through the sampler into the coarse network -- which is
+    what DietNeRF's consistency loss needs (src/DietNeRF.py:204-222: 55 + 55 samples).  Checked against float64
+    autograd of that graph for a random upstream d_rgb, with alpha = 1 (smooth network: bar 2e-4 of max|g|); then
+    accumulate = 1 on top of a train_gradients call gives the sum of the two gradients."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt, n=40, sc=55, sf=55, seed=9)
+    rng = np.random.default_rng(3)
+    d_rgb = (rng.standard_normal((40, 3)) * 0.1).astype(np.float32)
+    ctx = _ctx(p, leaky_relu_alpha=1.0)
+    ctx.train_begin(5e-4, sampler_gradient=sampler_gradient)
+    rgb, gc, gf = ctx.train_render_gradients(p["o"], p["d"], d_rgb, p["sc"], p["sf"], p["u_c"], p["u_f"])
+    r = T.render_gradients(p["bc"], p["bf"], p["o"], p["d"], d_rgb, p["near"], p["far"], p["u_c"], p["u_f"],
+                           sampler_grad=sampler_gradient, alpha=1.0)
+    # the forward it re-ran is the render path's: same rgb as nerf_render on the same draws
+    out = ctx.render(p["o"], p["d"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    assert np.abs(rgb - r["rgb"]).max() <= 5e-5 and np.abs(rgb - out[0]).max() <= 5e-5      # fp32 vs float64 forward
+    ef, cf = _relerr(gf, r["grad_fine"]), _cos(gf, r["grad_fine"])
+    with capsys.disabled():
+        print(f"\n[backward through render(), 40 rays x (55 + 55), sampler term {'on' if sampler_gradient else 'off'}] "
+              f"fine gradient vs float64 autograd {ef:.2e} of max|g|, cosine {cf:.7f}", end="")
+    assert ef <= 2e-4 and cf > 0.9999999
+    if sampler_gradient:
+        ec, cc = _relerr(gc, r["grad_coarse"]), _cos(gc, r["grad_coarse"])
+        with capsys.disabled():
+            print(f"; coarse (through the sampler only) {ec:.2e}, cosine {cc:.7f}")
+        assert ec <= 2e-4 and cc > 0.9999999
+    else:
+        assert not gc.any() and not r["grad_coarse"].any()      # render() does not depend on the coarse weights then
+    # sum with the ray loss, as the reference does before its single Adam step (src/DietNeRF.py:140-153)
+    m, gc1, gf1 = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    _, gc2, gf2 = ctx.train_render_gradients(p["o"], p["d"], d_rgb, p["sc"], p["sf"], p["u_c"], p["u_f"], accumulate=True)
+    assert np.abs(gf2 - (gf1 + gf)).max() <= 1e-6 * np.abs(gf2).max()
+    assert np.abs(gc2 - (gc1 + gc)).max() <= 1e-6 * max(np.abs(gc2).max(), 1e-30)
+    ctx.train_apply()
+    ctx.close()
+
+
 @pytest.mark.parametrize("alpha", [1.0, 0.05])
 def test_gradients_at_the_reference_sample_counts(oracle, golden_ckpt, alpha, capsys):
     """The float64 autograd oracle at the reference's own sample counts (64 coarse + 128 fine) on a 32-ray batch, sampler

@@ -74,6 +74,37 @@ def test_train_oracle_gradients_by_finite_differences(oracle, golden_ckpt):
     np.testing.assert_allclose(r["grad_fine"], r0["grad_fine"], rtol=0, atol=1e-12)
 
 
+def test_render_gradient_oracle(oracle, golden_ckpt):
+    """oracle.train_oracle.render_gradients (autograd through NeRF.render, src/NeRF.py:109-134): its forward equals the
+    pinned render oracle (fine pass on sort(concat)), its backward passes a finite-difference check, and the coarse
+    network receives gradient only through the sampler."""
+    from oracle import train_oracle as T
+    p = _setup(oracle, golden_ckpt)
+    rng = np.random.default_rng(4)
+    d_rgb = rng.standard_normal((p["o"].shape[0], 3))
+    args = (p["o"], p["d"], d_rgb, p["near"], p["far"], p["u_c"], p["u_f"])
+    r = T.render_gradients(p["bc"], p["bf"], *args)
+    ref = oracle.render(oracle.unpack_blob(p["bc"]), oracle.unpack_blob(p["bf"]), p["o"], p["d"], p["near"], p["far"],
+                        p["u_c"], p["u_f"])
+    assert np.abs(r["rgb"] - ref[0]).max() <= 1e-5
+
+    def value_at(which, i, h):
+        blobs = [p["bc"].astype(np.float64), p["bf"].astype(np.float64)]
+        blobs[which][i] += h
+        # render_gradients takes float32-convertible blobs: evaluate L = sum(d_rgb * rgb) from its own forward
+        q = T.render_gradients(blobs[0], blobs[1], *args)
+        return float((q["rgb"] * d_rgb).sum())
+
+    for which, g in ((0, r["grad_coarse"]), (1, r["grad_fine"])):
+        i = int(np.argmax(np.abs(g)))
+        h = 2e-3 * max(1e-3, abs(float((p["bc"] if which == 0 else p["bf"])[i])))      # blobs pass through float32
+        fd = (value_at(which, i, h) - value_at(which, i, -h)) / (2 * h)
+        assert abs(fd - g[i]) <= 3e-2 * abs(g[i]), (which, i, fd, g[i])
+    r0 = T.render_gradients(p["bc"], p["bf"], *args, sampler_grad=False)
+    assert not r0["grad_coarse"].any() and np.abs(r["grad_coarse"]).max() > 0
+    np.testing.assert_allclose(r["grad_fine"], r0["grad_fine"], rtol=0, atol=1e-12)
+
+
 def test_adam_known_answer():
     """Keras-2.7 Adam by hand for one scalar, two steps (lr 0.1, defaults)."""
     from oracle import train_oracle as T
