@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+#define NERF_ABI_VERSION 2
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
 enum { NERF_MEM_HOST = 0, NERF_MEM_DEVICE = 1 };
@@ -166,6 +166,16 @@ typedef struct nerf_train_config {
     float beta_1, beta_2;      /* Keras defaults 0.9, 0.999 */
     float epsilon;             /* Keras default 1e-7 */
     int32_t sampler_gradient;  /* 1 = reference behaviour; 0 = treat z_from_dist as data (classic NeRF) */
+    /* ABI 2: the reference's production policy (mixed_float16, src/ExecutionRun.py:220-221; loss-scaled branch of
+     * train_step, src/NeRF.py:159-163; LossScaleOptimizer, src/ExecutionRun.py:262).  0 = the fp32 policy (fp32-class
+     * products).  1 = fp16 compute: forward and data gradients with ONE fp16 MFMA pass per product, activations /
+     * gradients rounded to fp16 between layers, fp32 accumulation, fp32 master weights and weight gradients; the
+     * loss is scaled before the backward pass, gradients are unscaled and tested: a step with a non-finite gradient is
+     * SKIPPED and halves the scale, dynamic_growth_steps finite steps in a row double it (Keras 2.7 dynamic loss
+     * scaling: initial 2^15, growth interval 2000).  Not supported for the xyz-only network. */
+    int32_t mixed_float16;
+    float initial_loss_scale;      /* 0 -> 32768 */
+    int32_t dynamic_growth_steps;  /* 0 -> 2000 */
 } nerf_train_config;
 
 /* Starts a trainer on the weights currently loaded (coarse required, fine optional); zero Adam moments. */
@@ -173,6 +183,9 @@ int nerf_train_begin(nerf_ctx* ctx, const nerf_train_config* cfg);
 /* Packs the trained weights for the render path and frees optimizer state and activation buffers. */
 int nerf_train_end(nerf_ctx* ctx);
 int nerf_train_set_learning_rate(nerf_ctx* ctx, float learning_rate);
+/* mixed_float16 policy: the current loss scale, the optimizer steps applied and the steps skipped so far (1 / n / 0
+ * under the fp32 policy).  Any pointer may be NULL. */
+int nerf_train_loss_scale(nerf_ctx* ctx, float* loss_scale, int64_t* steps_applied, int64_t* steps_skipped);
 /* One NeRF.train_step on N rays: rays_orig/rays_dirs (N,4), target_rgb (N,3); u_coarse (N,Sc) / u_fine (N,Sf)
  * NULL -> on-device Philox(seed, ray index in the batch).  metrics (host, nullable): loss, psnr_coarse, psnr_fine;
  * passing it synchronises.  Sf = 0 (or no fine network) trains the coarse network alone (src/NeRF.py:153).

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NERF_MI355_LIB") or os.path.join(_HERE, "lib", "libne
 NERF_NET_COARSE, NERF_NET_FINE = 0, 1
 NERF_MEM_HOST, NERF_MEM_DEVICE = 0, 1
 NERF_PRECISION_FP32, NERF_PRECISION_F16X3, NERF_PRECISION_F16 = 0, 1, 2
-NERF_ABI_VERSION = 1
+NERF_ABI_VERSION = 2
 
 
 class NerfConfig(C.Structure):
@@ -29,7 +29,8 @@ class NerfConfig(C.Structure):
 
 class NerfTrainConfig(C.Structure):
     _fields_ = [("learning_rate", C.c_float), ("beta_1", C.c_float), ("beta_2", C.c_float),
-                ("epsilon", C.c_float), ("sampler_gradient", C.c_int32)]
+                ("epsilon", C.c_float), ("sampler_gradient", C.c_int32), ("mixed_float16", C.c_int32),
+                ("initial_loss_scale", C.c_float), ("dynamic_growth_steps", C.c_int32)]
 
 
 class NerfOutputs(C.Structure):
@@ -68,6 +69,7 @@ SYMBOLS = [
     ("nerf_train_begin", C.c_int, [_P, C.POINTER(NerfTrainConfig)]),
     ("nerf_train_end", C.c_int, [_P]),
     ("nerf_train_set_learning_rate", C.c_int, [_P, _F]),
+    ("nerf_train_loss_scale", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I64), C.POINTER(_I64)]),
     ("nerf_train_step", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, C.c_int]),
     ("nerf_train_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, _P, _P, C.c_int]),
     ("nerf_train_apply", C.c_int, [_P, _P, _P, C.c_int]),

@@ -38,6 +38,13 @@ constexpr int kBChunksXyz = (2 * 2 * 16) / kHCQ;                          // 2: 
 constexpr int kBStreamChunks = kBChunksHead + 7 * kBChunksHid;                                  // 61
 constexpr int kBStreamChunksDx = kBChunksHead + 6 * kBChunksHid + kBChunksHidX + kBChunksXyz;   // 65
 static_assert((size_t)kBStreamChunksDx * kHChunkBytes == kBwdStreamBytes, "backward stream size mismatch");
+// single-pass variant (mixed_float16 policy): hi fragments only, one quad per k-step
+constexpr int kBFChunksHead = (8 * kBStepsHead + kHCQ - 1) / kHCQ;        // 72 quads -> 3
+constexpr int kBFChunksHid = (8 * 16) / kHCQ;                             // 4
+constexpr int kBFChunksHidX = ((8 + 2) * 16) / kHCQ;                      // 5
+constexpr int kBFChunksXyz = (2 * 16) / kHCQ;                             // 1
+constexpr int kBFStreamChunks = kBFChunksHead + 7 * kBFChunksHid;                                   // 31
+constexpr int kBFStreamChunksDx = kBFChunksHead + 6 * kBFChunksHid + kBFChunksHidX + kBFChunksXyz;   // 33
 
 constexpr int kBConstWrgb = 2208;     // the forward kernel's constant block is reused: [3][128] rgb head weights
 constexpr int kBConstFloats = 2608;
@@ -81,7 +88,9 @@ __device__ __forceinline__ float mask_factor(uint32_t w, float alpha) {
 // epilogue of a tile is dealt out over the NEXT tile's k-steps and the last hidden tile is finished by the next body
 // (PEND).  copy_tail: the previous body staged its outputs in nh/nl (an in-place BW_HID body), so fragments 12..13
 // still have to move to xh/xl; after BW_HEAD (which writes xh/xl directly) they must not.
-template <int KIND, int NX, bool PEND>
+// FAST = the mixed_float16 policy's arithmetic: one fp16 MFMA pass per product (hi fragments only, their own stream),
+// the masked gradient rounded (RNE) to fp16 as the next operand; the per-sample scales work as before.
+template <int KIND, int NX, bool PEND, bool FAST>
 __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, BwdLane& L, bool copy_tail,
                                          float* d_prev, float* d_cur, float* dx_cur, const frag4& mk_prev,
                                          const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[4], frag4 (&xh)[16],
@@ -89,9 +98,10 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     constexpr int NH = KIND == BW_XYZ ? 0 : 8;
     constexpr int NU = NX + NH;
     constexpr int NSTEP = KIND == BW_HEAD ? kBStepsHead : 16;
-    constexpr int QPU = 2 * NSTEP;
+    constexpr int TPS = FAST ? 1 : 2;
+    constexpr int QPU = TPS * NSTEP;
     constexpr int NQ = NU * QPU;
-    constexpr int kPf = 4;
+    constexpr int kPf = FAST ? 8 : 4;
     f32x4 pf[kPf];
     const int ck0 = p.ck;
     uint32_t rdbase[2];
@@ -129,13 +139,19 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         L.mrun = fmaxf(L.mrun, fabsf(pk));
         if constexpr ((r & 1) == 0) pc = pk;
         else {
-            float h0, l0, h1, l1;
-            split_trunc(pc, h0, l0);
-            split_trunc(pk, h1, l1);
             constexpr int n = 2 * ht + (r >> 3), d = (r & 7) >> 1;
-            const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);
-            if constexpr (decltype(to_x)::value) { xh[n][d] = ph; xl[n][d] = pl; }
-            else { nh[n][d] = ph; nl[n][d] = pl; }
+            if constexpr (FAST) {
+                const uint32_t ph = pack_h2(pc, pk);
+                if constexpr (decltype(to_x)::value) xh[n][d] = ph;
+                else nh[n][d] = ph;
+            } else {
+                float h0, l0, h1, l1;
+                split_trunc(pc, h0, l0);
+                split_trunc(pk, h1, l1);
+                const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);
+                if constexpr (decltype(to_x)::value) { xh[n][d] = ph; xl[n][d] = pl; }
+                else { nh[n][d] = ph; nl[n][d] = pl; }
+            }
         }
     };
     auto xyz_reg = [&](auto xtc, auto rc, float acc_v) {
@@ -158,9 +174,9 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             f32x4 araw[2];
-            static_for<0, 2>([&](auto tc) {
+            static_for<0, TPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                constexpr int Q = u * QPU + 2 * n + t;
+                constexpr int Q = u * QPU + TPS * n + t;
                 constexpr int qc = Q % kHCQ;
                 if constexpr (qc == 0 && Q > 0) p.ck += 1;
                 if constexpr (qc == kHCQ / 2) {
@@ -182,21 +198,25 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                 }
             });
             const h8 a_hi = __builtin_bit_cast(h8, araw[0]);
-            const h8 a_lo = __builtin_bit_cast(h8, araw[1]);
+            const h8 a_lo = __builtin_bit_cast(h8, araw[FAST ? 0 : 1]);
+            (void)a_lo;
             frag4 bh_, bl_;
             if constexpr (KIND == BW_HEAD) { bh_ = nh[n]; bl_ = nl[n]; }
             else { bh_ = xh[n]; bl_ = xl[n]; }
             const h8 b_hi = __builtin_bit_cast(h8, bh_), b_lo = __builtin_bit_cast(h8, bl_);
-            if constexpr (n == 0) {
-                f32x16 zero;
+            (void)b_lo;
+            f32x16 zero;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, zero, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+            if constexpr (FAST) {
+                if constexpr (n == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, zero, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
             } else {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+                if constexpr (n == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, zero, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
 
             // ---- deferred epilogues ----
             if constexpr (u == 0 && PEND) {
@@ -251,7 +271,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     p.ck += 1;
 }
 
-template <bool DX>
+template <bool DX, bool FAST>
 __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -272,7 +292,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = DX ? kBStreamChunksDx : kBStreamChunks;
+    p.n_chunks = FAST ? (DX ? kBFStreamChunksDx : kBFStreamChunks) : (DX ? kBStreamChunksDx : kBStreamChunks);
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
@@ -339,6 +359,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         for (int n = 0; n < 8; ++n) {
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
+                if constexpr (FAST) {
+                    nh[n][e >> 1] = pack_h2(g9[n * 8 + e] * sig, g9[n * 8 + e + 1] * sig);
+                    nl[n][e >> 1] = 0u;
+                    continue;
+                }
                 float h0, l0, h1, l1;
                 split_trunc(g9[n * 8 + e] * sig, h0, l0);
                 split_trunc(g9[n * 8 + e + 1] * sig, h1, l1);
@@ -348,7 +373,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         }
         {   // the sigma head's rank-1 term rides as a 9th k-step: element 0 of lane half 0 = d_sigma
             float h0, l0;
-            split_trunc(h ? 0.f : graw[3] * sig, h0, l0);
+            if constexpr (FAST) { h0 = h ? 0.f : graw[3] * sig; l0 = 0.f; }
+            else split_trunc(h ? 0.f : graw[3] * sig, h0, l0);
             nh[8] = frag4{pack_h2(h0, 0.f), 0u, 0u, 0u};
             nl[8] = frag4{pack_h2(l0, 0.f), 0u, 0u, 0u};
         }
@@ -359,7 +385,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         float* dxa = DX ? a.dx_ptr[0] + m * kBwdXyzLd + 4 * h : nullptr;
         float* dxb = DX ? a.dx_ptr[1] + m * kBwdXyzLd + 4 * h : nullptr;
         frag4 mk_prev = mq[1], mk_cur = mq[1];
-        bwd_body<BW_HEAD, 0, false>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
+        bwd_body<BW_HEAD, 0, false, FAST>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
                                     nh, nl);
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {         // body of layer l: consumes D_l, produces D_(l-1)
@@ -374,16 +400,16 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             d_cur = a.d_ptr[l - 1] + off256;
             const int gslot_prev = 8 - l;          // slot k <-> D_(8-k)
             if (DX && l == 4)
-                bwd_body<BW_HID, DX ? 2 : 0, true>(p, lane16, alpha, L, true, d_prev, d_cur, dxa, mk_prev, mk_cur,
+                bwd_body<BW_HID, DX ? 2 : 0, true, FAST>(p, lane16, alpha, L, true, d_prev, d_cur, dxa, mk_prev, mk_cur,
                                                    gslot_prev, accs, xh, xl, nh, nl);
             else
-                bwd_body<BW_HID, 0, true>(p, lane16, alpha, L, l != 7, d_prev, d_cur, nullptr, mk_prev, mk_cur, gslot_prev,
+                bwd_body<BW_HID, 0, true, FAST>(p, lane16, alpha, L, l != 7, d_prev, d_cur, nullptr, mk_prev, mk_cur, gslot_prev,
                                           accs, xh, xl, nh, nl);
         }
         L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
         L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
         if constexpr (DX) {
-            bwd_body<BW_XYZ, 2, true>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, 8, accs, xh, xl, nh, nl);
+            bwd_body<BW_XYZ, 2, true, FAST>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, 8, accs, xh, xl, nh, nl);
         } else {
             // flush: D0's last tile has no chain to ride on; nothing is packed any more
             f32x16& last = accs[3];
@@ -414,29 +440,30 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_kernel(const MlpBwdArgs a) { mlp_bwd_body<false>(a); }
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, false>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, false>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true>(a); }
 
-void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, int num_cus, hipStream_t stream) {
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream) {
     if (a.Mp <= 0) return;
     const long long ntiles = a.Mp / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    if (dx) hipLaunchKernelGGL(mlp_bwd_f16x3_dx_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
-    else hipLaunchKernelGGL(mlp_bwd_f16x3_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    auto* k = single_pass ? (dx ? mlp_bwd_f16_dx_kernel : mlp_bwd_f16_kernel)
+                          : (dx ? mlp_bwd_f16x3_dx_kernel : mlp_bwd_f16x3_kernel);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
 void mlp_bwd_f16x3_set_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_f16x3_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_f16x3_dx_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    for (auto* k : {mlp_bwd_f16x3_kernel, mlp_bwd_f16x3_dx_kernel, mlp_bwd_f16_kernel, mlp_bwd_f16_dx_kernel})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
 // ------------------------------------------------------------------------------------------------
 // The backward stream as an index map (host): idx[slot] = 2 * (src + 1) + is_lo, 0 = padding; src = index into the
 // blob (Keras get_weights() order).  Re-packed on the device after every optimizer step by repack_bwd_kernel.
 // ------------------------------------------------------------------------------------------------
-void build_bwd_gather(int n_angles, bool dx, int32_t* idx /* kBwdStreamBytes / 2 entries */) {
+void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdStreamBytes / 2 entries */) {
     memset(idx, 0, (kBwdStreamBytes / 2) * sizeof(int32_t));
     const int kd = 256 + 8 * (n_angles + 1);
     const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
@@ -453,11 +480,15 @@ void build_bwd_gather(int n_angles, bool dx, int32_t* idx /* kBwdStreamBytes / 2
                     for (int e = 0; e < 8; ++e) {
                         const long long s = src(u, lane & 31, n, e, lane >> 5);
                         if (s < 0) continue;
+                        if (hi_only) {
+                            idx[b0 + (long long)(u * NSTEP + n) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1));
+                            continue;
+                        }
                         const long long q = (long long)(u * NSTEP + n) * 2;
                         idx[b0 + (q + 0) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1));
                         idx[b0 + (q + 1) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1) + 1);
                     }
-        chunk += (NU * NSTEP * 2 + kHCQ - 1) / kHCQ;
+        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kHCQ - 1) / kHCQ;
     };
     // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step)
     emit(8, kBStepsHead, [&](int u, int i, int n, int e, int h) -> long long {

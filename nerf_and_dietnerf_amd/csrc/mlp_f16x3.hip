@@ -523,14 +523,16 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_kernel(const MlpArgs a) { mlp_f16_body<false>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16_kernel(const MlpArgs a) { mlp_f16_body<true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_stash_kernel(const MlpArgs a) { mlp_f16_body<false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16_stash_kernel(const MlpArgs a) { mlp_f16_body<true, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_xyz_kernel(const MlpArgs a) { mlp_f16_body<false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16_xyz_kernel(const MlpArgs a) { mlp_f16_body<true, false, true>(a); }
 
-void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream) {
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 127) / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    hipLaunchKernelGGL(mlp_f16x3_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    if (single_pass) hipLaunchKernelGGL(mlp_f16_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    else hipLaunchKernelGGL(mlp_f16x3_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass, bool xyz_only) {
@@ -559,6 +561,8 @@ void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_stash_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_stash_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_xyz_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
@@ -717,23 +721,24 @@ static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_
 
 // gather tables of the 3-pass stream for the device-side re-pack (the trainer's forward runs on this kernel and its
 // weights change every step): stream_idx[slot] = 2 * (src + 1) + is_lo, const_idx[float] = src + 1; 0 = padding
-void build_f16x3_gather(int n_angles, int32_t* stream_idx /*kStreamBytesF16 / 2*/, int32_t* const_idx /*kConstFloats*/) {
-    memset(stream_idx, 0, (kStreamBytesF16 / 2) * sizeof(int32_t));
+void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /*kStreamBytesF16[Hi] / 2*/,
+                        int32_t* const_idx /*kConstFloats*/) {
+    memset(stream_idx, 0, ((hi_only ? kStreamBytesF16Hi : kStreamBytesF16) / 2) * sizeof(int32_t));
     memset(const_idx, 0, kConstFloats * sizeof(int32_t));
-    pack_f16_map(n_angles, false,
+    pack_f16_map(n_angles, hi_only,
                  [&](long long ph, long long pl, long long src) {
                      if (src < 0) return;
                      stream_idx[ph] = (int32_t)(2 * (src + 1));
-                     stream_idx[pl] = (int32_t)(2 * (src + 1) + 1);
+                     if (pl >= 0) stream_idx[pl] = (int32_t)(2 * (src + 1) + 1);
                  },
                  [&](long long pos, long long src) { const_idx[pos] = (int32_t)(src + 1); });
 }
 
 __global__ void repack_f16x3_kernel(const float* __restrict__ blob, const int32_t* __restrict__ stream_idx,
                                     uint16_t* __restrict__ stream, const int32_t* __restrict__ const_idx,
-                                    float* __restrict__ cst) {
+                                    float* __restrict__ cst, size_t n_slots) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < kStreamBytesF16 / 2) {
+    if (i < n_slots) {
         const int32_t t = stream_idx[i];
         uint16_t out = 0;
         if (t != 0) {
@@ -751,10 +756,10 @@ __global__ void repack_f16x3_kernel(const float* __restrict__ blob, const int32_
 }
 
 void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
-                         hipStream_t s) {
-    const size_t n = kStreamBytesF16 / 2;
+                         bool hi_only, hipStream_t s) {
+    const size_t n = (hi_only ? kStreamBytesF16Hi : kStreamBytesF16) / 2;
     hipLaunchKernelGGL(repack_f16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blob, stream_idx,
-                       reinterpret_cast<uint16_t*>(stream), const_idx, cst);
+                       reinterpret_cast<uint16_t*>(stream), const_idx, cst, n);
 }
 
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out) {

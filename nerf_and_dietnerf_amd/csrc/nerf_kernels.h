@@ -86,11 +86,13 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStr
 // mlp_f16x3.hip
 // single_pass: hi*hi only; xyz_only: the 12-layer network without view directions (its own streams / constants)
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false, bool xyz_only = false);
-void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream);   // 3-pass forward that also writes a.st_ptr
-// device-side re-pack of the 3-pass stream + constants from a blob (tables from build_f16x3_gather, host)
-void build_f16x3_gather(int n_angles, int32_t* stream_idx /*kStreamBytesF16/2*/, int32_t* const_idx /*kConstFloats*/);
+// forward that also writes a.st_ptr / a.mask_ptr (training); single_pass: the mixed_float16-class arithmetic
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);
+// device-side re-pack of the 3-pass (or hi-only) stream + constants from a blob (tables from build_f16x3_gather, host)
+void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /*kStreamBytesF16[Hi]/2*/,
+                        int32_t* const_idx /*kConstFloats*/);
 void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
-                         hipStream_t s);
+                         bool hi_only, hipStream_t s);
 void mlp_f16x3_set_attributes();
 // stream_out: kStreamBytesF16 / kStreamBytesF16Hi bytes (kStreamBytesF16Xyz / kStreamBytesF16HiXyz when n_angles == 0)
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
@@ -110,9 +112,10 @@ struct MlpBwdArgs {
     long long Mp;            // rows, multiple of 128
     float alpha;
 };
-void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, int num_cus, hipStream_t stream);
+// single_pass: hi*hi products only, gradients rounded to fp16 between layers (the mixed_float16 policy's backward)
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream);
 void mlp_bwd_f16x3_set_attributes();
-void build_bwd_gather(int n_angles, bool dx, int32_t* idx /* kBwdStreamBytes / 2 */);
+void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdStreamBytes / 2 */);
 void launch_repack_bwd(const float* blob, const int32_t* idx, void* stream, hipStream_t s);
 
 // aux_kernels.hip

@@ -59,6 +59,14 @@ struct TrainState {
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
     bool acc_grads = false;         // the running backward pass ADDS to the gradient blobs (nerf_train_render_gradients)
+    // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients
+    // and the dynamic loss scale of Keras' LossScaleOptimizer
+    bool mixed = false;
+    float loss_scale = 1.f;
+    int good_steps = 0, growth_steps = 2000;
+    long long skipped = 0;
+    bool last_finite = true;        // verdict of the latest gradients (unscale + finiteness test)
+    DevBuf flag;                    // device int: all gradients finite
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
@@ -94,7 +102,8 @@ int layer_table(const nerf_config& cfg, TLayer L[12]) {
 void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 int relayout_net(nerf_ctx* c, TNet& n) {
-    if (n.fstream) launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->stream);
+    if (n.fstream)
+        launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->train->mixed, c->stream);
     if (n.bstream) launch_repack_bwd(n.blob, c->train->bidx[n.bdx ? 1 : 0], n.bstream, c->stream);
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
@@ -123,8 +132,8 @@ int alloc_optimizer(nerf_ctx* c, TrainState* t, TNet& n) {
 int ensure_fused(nerf_ctx* c, TrainState* t, TNet& n) {
     if (!t->fused_forward) return 0;
     if (!t->sidx) {
-        std::vector<int32_t> si(kStreamBytesF16 / 2), ci(kConstFloats);
-        build_f16x3_gather(c->cfg.n_angles, si.data(), ci.data());
+        std::vector<int32_t> si(kStreamBytesF16 / 2), ci(kConstFloats);       // (the hi-only table uses its first half)
+        build_f16x3_gather(c->cfg.n_angles, t->mixed, si.data(), ci.data());
         HIP_OK(hipMalloc((void**)&t->sidx, si.size() * sizeof(int32_t)));
         HIP_OK(hipMalloc((void**)&t->cidx, ci.size() * sizeof(int32_t)));
         HIP_OK(hipMemcpy(t->sidx, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -138,7 +147,7 @@ int ensure_fused(nerf_ctx* c, TrainState* t, TNet& n) {
         int32_t*& bi = t->bidx[n.bdx ? 1 : 0];
         if (!bi) {
             std::vector<int32_t> idx(kBwdStreamBytes / 2);
-            build_bwd_gather(c->cfg.n_angles, n.bdx, idx.data());
+            build_bwd_gather(c->cfg.n_angles, n.bdx, t->mixed, idx.data());
             HIP_OK(hipMalloc((void**)&bi, idx.size() * sizeof(int32_t)));
             HIP_OK(hipMemcpy(bi, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
@@ -256,7 +265,7 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
             a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
         }
         { const char* dw = getenv("NERF_DIAG_STASH_WRAP"); a.diag_wrap = dw && dw[0] == '1'; }   // timing diagnostic: wrong results
-        launch_mlp_f16x3_stash(a, c->num_cus, c->stream);
+        launch_mlp_f16x3_stash(a, c->num_cus, c->stream, t->mixed);
     } else {
         forward_layers(c, n, p, d.Mp, raw);
     }
@@ -347,7 +356,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
             b.d_ptr[l] = (float*)p.D[l].p;
         }
         b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
-        launch_mlp_bwd_f16x3(b, n.bdx, c->num_cus, c->stream);
+        launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream);
         wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
         wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], 128, 128, 0, Mp, GM(0));
@@ -470,7 +479,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, (float*)pf.z.p, nullptr,
                           c->stream);
         if (int q = forward_pass(c, t, 1, df, o, d)) return q;
-        launch_mse((const float*)pf.rgb.p, tg, N, d_rgb, scal + 1, c->stream);
+        launch_mse((const float*)pf.rgb.p, tg, N, t->loss_scale, d_rgb, scal + 1, c->stream);
         HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
         float* d_zf = through_sampler ? (float*)t->d_zf.p : nullptr;
         launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sf, d_rgb, nullptr,
@@ -480,12 +489,41 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
             launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, d_zf,
                                   (float*)t->d_wext.p, c->stream);
     }
-    launch_mse((const float*)pc.rgb.p, tg, N, d_rgb, scal + 0, c->stream);
+    launch_mse((const float*)pc.rgb.p, tg, N, t->loss_scale, d_rgb, scal + 0, c->stream);
     HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
     launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, d_rgb,
                          through_sampler ? (const float*)t->d_wext.p : nullptr, Graw, nullptr, c->stream);
     if (int q = backward_pass(c, t, 0, dc, o, d, nullptr)) return q;
+    if (t->mixed) {
+        // LossScaleOptimizer: unscale, test for Inf/NaN; the verdict decides in finish_loss_scale() whether the step is
+        // applied.  (The per-sample scaling of the backward chain makes the products themselves scale-invariant; the
+        // loss scale still guards the compositing / sampler backward and gives the reference's skip-step behaviour.)
+        if (int q = ensure(c, t->flag, sizeof(int))) return q;
+        const int one = 1;
+        HIP_OK(hipMemcpyAsync(t->flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        launch_unscale_check(t->net[0].grad, fine ? t->net[1].grad : nullptr, t->nblob, 1.0f / t->loss_scale,
+                             (int*)t->flag.p, c->stream);
+    }
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// mixed_float16 policy: read the finiteness verdict of the gradients just computed and move the dynamic loss scale
+// (Keras 2.7 LossScaleOptimizer: halve on a non-finite step, double after `growth_steps` finite ones).
+int finish_loss_scale(nerf_ctx* c) {
+    TrainState* t = c->train;
+    if (!t->mixed) { t->last_finite = true; return 0; }
+    int ok = 1;
+    HIP_OK(hipMemcpyAsync(&ok, t->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    t->last_finite = ok != 0;
+    if (t->last_finite) {
+        if (++t->good_steps >= t->growth_steps) { t->loss_scale *= 2.f; t->good_steps = 0; }
+    } else {
+        t->loss_scale = t->loss_scale > 1.f ? t->loss_scale * 0.5f : 1.f;
+        t->good_steps = 0;
+        t->skipped += 1;
+    }
     return 0;
 }
 
@@ -641,7 +679,7 @@ void train_free(nerf_ctx* c) {
         for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
-                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb};
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->flag};
     for (DevBuf* b : bs) free_buf(*b);
     delete t;
     c->train = nullptr;
@@ -724,6 +762,13 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     t->cfg = *cfg;
     t->training = true;
     t->step = 0;
+    t->mixed = cfg->mixed_float16 != 0;
+    if (t->mixed && c->cfg.n_angles == 0) { train_free(c); return fail("mixed_float16 training is not built for the xyz-only network"); }
+    t->loss_scale = t->mixed ? (cfg->initial_loss_scale > 0.f ? cfg->initial_loss_scale : 32768.f) : 1.f;
+    t->growth_steps = cfg->dynamic_growth_steps > 0 ? cfg->dynamic_growth_steps : 2000;
+    t->good_steps = 0;
+    t->skipped = 0;
+    t->last_finite = true;
     // forward on the fused kernel unless the network has no fused kernel (xyz-only) or NERF_TRAIN_FORWARD=gemm asks
     // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
     const char* fw = getenv("NERF_TRAIN_FORWARD");
@@ -739,6 +784,11 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // for the layer-by-layer GEMMs; it reads the forward's mask records, so it needs the fused forward
     const char* bw = getenv("NERF_TRAIN_BACKWARD");
     t->fused_backward = t->fused_forward && t->dgrad_f16 && !(bw && strcmp(bw, "layers") == 0);
+    if (t->mixed && !(t->fused_forward && t->fused_backward)) {
+        train_free(c);
+        return fail("mixed_float16 training runs on the fused forward / backward kernels: unset NERF_TRAIN_FORWARD / "
+                    "NERF_TRAIN_BACKWARD / NERF_TRAIN_DGRAD / NERF_TRAIN_WGRAD");
+    }
     for (int w = 0; w < 2; ++w) {
         if (!c->net[w].loaded) continue;
         if (!t->net[w].present) {
@@ -770,6 +820,14 @@ int nerf_train_end(nerf_ctx* c) {
     return 0;
 }
 
+int nerf_train_loss_scale(nerf_ctx* c, float* loss_scale, int64_t* steps_applied, int64_t* steps_skipped) {
+    if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
+    if (loss_scale) *loss_scale = c->train->loss_scale;
+    if (steps_applied) *steps_applied = c->train->step;
+    if (steps_skipped) *steps_skipped = c->train->skipped;
+    return 0;
+}
+
 int nerf_train_set_learning_rate(nerf_ctx* c, float lr) {
     if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
     if (!(lr > 0.f)) return fail("learning_rate must be positive");
@@ -784,6 +842,7 @@ int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_
     if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
     TrainState* t = c->train;
     const bool fine = Sf > 0 && t->net[1].present;
+    if (int r = finish_loss_scale(c)) return r;          // mixed_float16: nerf_train_apply skips a non-finite step
     const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
     if (grad_fine) {
@@ -825,6 +884,7 @@ int nerf_train_apply(nerf_ctx* c, const float* grad_coarse, const float* grad_fi
         HIP_OK(hipMemcpyAsync(t->net[1].grad, grad_fine, t->nblob * sizeof(float), kind, c->stream));
     }
     if (mem == NERF_MEM_HOST && (grad_coarse || grad_fine)) HIP_OK(hipStreamSynchronize(c->stream));
+    if (t->mixed && !t->last_finite) return 0;          // LossScaleOptimizer.apply_gradients skips this step
     return apply_impl(c);
 }
 
@@ -841,7 +901,12 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
     for (int w = 0; w < 2; ++w)
         if (c->train->net[w].present)
             if (int r = comm_allreduce_mean(c, c->train->net[w].grad, c->train->nblob)) return r;
-    if (int r = apply_impl(c)) return r;
+    // (a non-finite shard gradient makes the all-reduced blob non-finite on every rank: ranks agree by themselves only
+    //  when the test runs after the all-reduce -- single-rank here; the data-parallel path is nerf_train_gradients +
+    //  the caller's all-reduce + nerf_train_apply, where the caller shares the verdict)
+    if (int r = finish_loss_scale(c)) return r;
+    if (c->train->last_finite)
+        if (int r = apply_impl(c)) return r;
     return read_metrics(c, fine, metrics);
 }
 

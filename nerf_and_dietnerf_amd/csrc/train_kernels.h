@@ -75,7 +75,9 @@ void launch_relayout(const RelayoutArgs& a, hipStream_t s);
 // rows [row0, row0 + M) of the sample grid (rays x S, or xyz/view rows in xyz_mode) -> local rows 0..M of C4/C8
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
                          long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s);
-void launch_mse(const float* rgb, const float* target, long long N, float* d_rgb, float* mse_out, hipStream_t s);
+void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
+                hipStream_t s);
+void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, float inv_scale, int* all_finite, hipStream_t s);
 void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
                           const float* d_w_ext, float* Graw, float* d_z, hipStream_t s);
 void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,

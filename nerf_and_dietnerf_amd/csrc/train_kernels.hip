@@ -887,9 +887,10 @@ void launch_train_encode(const float* o, const float* d, const float* z, long lo
 // One workgroup, fixed reduction order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
-                                                  long long n3, float* __restrict__ d_rgb, float* __restrict__ out) {
+                                                  long long n3, float loss_scale, float* __restrict__ d_rgb,
+                                                  float* __restrict__ out) {
     __shared__ float red[256];
-    const float scale = 2.0f / (float)n3;
+    const float scale = loss_scale * 2.0f / (float)n3;      // loss_scale: LossScaleOptimizer.get_scaled_loss (1 = none)
     float s = 0.f;
     for (long long i = threadIdx.x; i < n3; i += 256) {
         const float e = rgb[i] - tgt[i];
@@ -905,8 +906,33 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb,
     if (threadIdx.x == 0) out[0] = red[0] / (float)n3;
 }
 
-void launch_mse(const float* rgb, const float* target, long long N, float* d_rgb, float* mse_out, hipStream_t s) {
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, s, rgb, target, N * 3, d_rgb, mse_out);
+void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
+                hipStream_t s) {
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, s, rgb, target, N * 3, loss_scale, d_rgb, mse_out);
+}
+
+// LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
+// as one entry of either blob is Inf/NaN (the caller sets it to 1 first).
+__global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, float inv_scale,
+                                     int* __restrict__ all_finite) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const float a = ga[i] * inv_scale;
+        ga[i] = a;
+        bad = !(fabsf(a) <= 3.0e38f);
+        if (gb) {
+            const float b = gb[i] * inv_scale;
+            gb[i] = b;
+            bad |= !(fabsf(b) <= 3.0e38f);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *all_finite = 0;
+}
+
+void launch_unscale_check(float* ga, float* gb, size_t n, float inv_scale, int* all_finite, hipStream_t s) {
+    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, inv_scale,
+                       all_finite);
 }
 
 // ------------------------------------------------------------------------------------------------

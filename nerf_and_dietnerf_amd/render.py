@@ -198,10 +198,20 @@ class Context:
 
     # ---- training (NeRF.train_step, src/NeRF.py:136-178) ----
     def train_begin(self, learning_rate: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
-                    sampler_gradient: bool = True) -> None:
-        """Adam(lr) as model.compile(optimizer=Adam(optimizer_lr)) (src/ExecutionRun.py:226-227)."""
-        cfg = NerfTrainConfig(learning_rate, beta_1, beta_2, epsilon, 1 if sampler_gradient else 0)
+                    sampler_gradient: bool = True, mixed_float16: bool = False, initial_loss_scale: float = 0.0,
+                    dynamic_growth_steps: int = 0) -> None:
+        """Adam(lr) as model.compile(optimizer=Adam(optimizer_lr)) (src/ExecutionRun.py:226-227).
+        ``mixed_float16=True`` is the reference's production policy (src/ExecutionRun.py:220-221): fp16 compute with
+        fp32 master weights and Keras' dynamic loss scaling (LossScaleOptimizer; src/NeRF.py:159-163)."""
+        cfg = NerfTrainConfig(learning_rate, beta_1, beta_2, epsilon, 1 if sampler_gradient else 0,
+                              1 if mixed_float16 else 0, float(initial_loss_scale), int(dynamic_growth_steps))
         _lib.check(self.lib.nerf_train_begin(self.h, C.byref(cfg)))
+
+    def train_loss_scale(self) -> Tuple[float, int, int]:
+        """(current loss scale, optimizer steps applied, steps skipped) -- (1, n, 0) under the fp32 policy."""
+        s, a, k = C.c_float(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib.nerf_train_loss_scale(self.h, C.byref(s), C.byref(a), C.byref(k)))
+        return float(s.value), int(a.value), int(k.value)
 
     def train_end(self) -> None:
         _lib.check(self.lib.nerf_train_end(self.h))
@@ -490,8 +500,10 @@ class NeRF:
 
     # ---- training: model.compile(optimizer=Adam(lr)) + train_step (src/ExecutionRun.py:226-227, src/NeRF.py:136-178)
     def compile(self, optimizer_lr: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
-                sampler_gradient: bool = True) -> None:
-        self.ctx.train_begin(optimizer_lr, beta_1, beta_2, epsilon, sampler_gradient)
+                sampler_gradient: bool = True, mixed_float16: bool = False, initial_loss_scale: float = 0.0,
+                dynamic_growth_steps: int = 0) -> None:
+        self.ctx.train_begin(optimizer_lr, beta_1, beta_2, epsilon, sampler_gradient, mixed_float16, initial_loss_scale,
+                             dynamic_growth_steps)
         self._train_calls = 0
 
     def train_step(self, data, *, u_coarse=None, u_fine=None, seed=None, group=None) -> Dict[str, float]:
