@@ -336,14 +336,32 @@ def main():
         e_tr = (time.perf_counter() - t2) / k_tr
         m_tr = model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=99)
         model.ctx.train_end()
+        # the reference's production policy (mixed_float16 + dynamic loss scaling) on the same batch
+        model.compile(5e-4, mixed_float16=True)
+        for i in range(2):
+            model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=i, want_metrics=False)
+        sync()
+        t2m = time.perf_counter()
+        for i in range(k_tr):
+            model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=10 + i, want_metrics=False)
+        sync()
+        e_mx = (time.perf_counter() - t2m) / k_tr
+        ls_mx = model.ctx.train_loss_scale()
+        model.ctx.train_end()
         tf_tr = 3 * n_tr * (SC + SF) * FLOPS_PER_ROW / e_tr / 1e12
         train = {"metric": "train_step (NeRF.train_step: coarse+fine forward, backward incl. sampler, Adam)",
                  "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                  "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
                  "loss_finite": bool(m_tr["loss"] == m_tr["loss"]),
+                 "mixed_float16_policy": {"ms_per_step": e_mx * 1e3, "value": n_tr / e_mx, "unit": "rays/s",
+                                          "loss_scale": ls_mx[0], "steps_skipped": ls_mx[2],
+                                          "note": "single-pass fp16 forward + data gradients, dynamic loss scaling "
+                                                  "(src/ExecutionRun.py:220-221, src/NeRF.py:159-163); weight "
+                                                  "gradients stay on split operands"},
                  "roofline": {"bound": "mfma",
-                              "kernel": "whole step: mlp_f16x3_stash_kernel (fused forward) + gemm_abt_h / gemm_atb_h "
-                                        "(data / weight gradients), all 3-pass split-fp16 MFMA with fp32 accumulation",
+                              "kernel": "whole step: mlp_f16x3_stash_kernel (fused forward) + mlp_bwd_f16x3[_dx]_kernel "
+                                        "(fused data-gradient chain) + gemm_atb_h (weight gradients), all 3-pass "
+                                        "split-fp16 MFMA with fp32 accumulation",
                               "achieved": tf_tr, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
                               "frac": tf_tr / PEAK_TFLOPS["f16x3"], "frac_vs_fp32_matrix_peak": tf_tr / PEAK_TFLOPS["f32"],
                               "mfma_passes_per_product": 3,

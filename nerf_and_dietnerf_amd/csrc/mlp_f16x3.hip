@@ -24,58 +24,6 @@ namespace nerf {
 __device__ unsigned long long g_stamps_h[16];
 #endif
 
-// ---- stream geometry (quads of 1 KiB = one fp16 A fragment: 64 lanes x 8 halfs) ----
-constexpr int kHStepsPE = 3;      // 33 inputs -> 48 slots
-constexpr int kHStepsHid = 16;
-constexpr int kHStepsDir = 2;     // 24 inputs -> 32 slots
-constexpr int kHQpuPE = 2 * kHStepsPE;                       // hi + lo fragment per k-step
-constexpr int kHQpuHid = 2 * kHStepsHid;
-constexpr int kHQpuSkip = kHQpuPE + kHQpuHid;
-constexpr int kHQpuLast = kHQpuHid + 2 * kHStepsDir;
-constexpr int kHTilesLast = 5;    // 4 x 32 features of layer 8 + the sigma row
-constexpr int kHChunksPE = (8 * kHQpuPE + kHCQ - 1) / kHCQ;          // 2
-constexpr int kHChunksHid = (8 * kHQpuHid) / kHCQ;                   // 8
-constexpr int kHChunksSkip = (8 * kHQpuSkip + kHCQ - 1) / kHCQ;      // 10
-constexpr int kHChunksLast = (kHTilesLast * kHQpuLast + kHCQ - 1) / kHCQ;   // 6
-constexpr int kHStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kHChunksLast;   // 66
-// single-pass mode: its own stream with the hi fragments only (one quad per k-step)
-constexpr int kFChunksPE = (8 * kHStepsPE + kHCQ - 1) / kHCQ;                          // 1
-constexpr int kFChunksHid = (8 * kHStepsHid) / kHCQ;                                   // 4
-constexpr int kFChunksSkip = (8 * (kHStepsPE + kHStepsHid) + kHCQ - 1) / kHCQ;         // 5
-constexpr int kFChunksLast = (kHTilesLast * (kHStepsHid + kHStepsDir) + kHCQ - 1) / kHCQ;   // 3
-constexpr int kFStreamChunks = kFChunksPE + 6 * kFChunksHid + kFChunksSkip + kFChunksLast;  // 33
-static_assert(kFStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16Hi, "hi-only stream size mismatch");
-// constant region (floats)
-constexpr int kHConstBias = 0;        // 8 x 256
-constexpr int kHConstBias8 = 2048;    // 128
-constexpr int kHConstBiasSig = 2176;  // 32: row 0 = sigma bias
-constexpr int kHConstWrgb = 2208;     // [3][128]
-constexpr int kHConstBHead = 2592;    // b_r, b_g, b_b, (unused)
-constexpr int kHConstFloats = 2608;
-
-static_assert(kHStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16, "stream size mismatch");
-// xyz-only network (n_angles_for_model = 0, src/NeRF.py:248-288): ... -> h8 -> [sigma | dense 256] -> dense 128 -> rgb.
-// Its tail replaces BODY_LAST by two bodies: BODY_HIDSIG (the extra 256-wide layer with the sigma row as a LEADING 9th
-// tile: sigma reads h8, this body's input) and BODY_LAST0 (256 -> 128, no direction k-steps, no sigma tile).
-constexpr int kXChunksHidSig = (9 * kHQpuHid) / kHCQ;                   // 9
-constexpr int kXChunksLast0 = (4 * kHQpuHid) / kHCQ;                    // 4
-constexpr int kXStreamChunks = kHChunksPE + 6 * kHChunksHid + kHChunksSkip + kXChunksHidSig + kXChunksLast0;   // 73
-constexpr int kXFChunksHidSig = (9 * kHStepsHid + kHCQ - 1) / kHCQ;     // 5
-constexpr int kXFChunksLast0 = (4 * kHStepsHid) / kHCQ;                 // 2
-constexpr int kXFStreamChunks = kFChunksPE + 6 * kFChunksHid + kFChunksSkip + kXFChunksHidSig + kXFChunksLast0;   // 37
-static_assert(kXStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16Xyz, "xyz-only stream size mismatch");
-static_assert(kXFStreamChunks * (size_t)kHChunkBytes == kStreamBytesF16HiXyz, "xyz-only hi stream size mismatch");
-// constant region of the xyz-only variant (floats): 8 x 256 biases as above, then
-constexpr int kXConstBiasSig = 2048;  // 32: row 0 = sigma bias (the leading tile of BODY_HIDSIG)
-constexpr int kXConstBias8 = 2080;    // 256: the extra hidden layer
-constexpr int kXConstBias9 = 2336;    // 128
-constexpr int kXConstWrgb = 2464;     // [3][128]
-constexpr int kXConstBHead = 2848;    // b_r, b_g, b_b, (unused)
-constexpr int kXConstFloats = 2864;
-static_assert(kXConstFloats <= kConstFloats, "xyz-only constants must fit the shared LDS carve");
-enum { BODY_HIDSIG = 4, BODY_LAST0 = 5 };
-static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
-
 // One dense layer on the fp16 matrix cores, u-outer (one accumulator chain per 32-wide output tile).
 // The epilogue of a tile (bias, LeakyReLU, hi/lo split, fp16 pack) is dealt out ONE accumulator
 // register per k-step over the NEXT tile's chain -- also across layer boundaries (PENDING: the

@@ -8,6 +8,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -153,7 +154,11 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
         c->timed_rows += M;
         HIP_OK(hipEventRecord(e0, c->stream));
     }
-    if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16, c->cfg.n_angles == 0);
+    // single-pass mode: two sample tiles per wave (half the weight stream per row) unless NERF_F16_TILES=1 asks for the
+    // one-tile kernel; the xyz-only network has the one-tile variant only
+    static const bool one_tile = [] { const char* e = getenv("NERF_F16_TILES"); return e && e[0] == '1'; }();
+    if (c->cfg.precision == NERF_PRECISION_F16 && c->cfg.n_angles != 0 && !one_tile) launch_mlp_f16_2t(a, c->num_cus, c->stream);
+    else if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16, c->cfg.n_angles == 0);
     else launch_mlp_fp32(a, c->num_cus, c->stream);
     if (c->timing) HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipGetLastError());
@@ -281,6 +286,7 @@ int nerf_ctx_create(const nerf_config* cfg, nerf_ctx** out) {
     mlp_fp32_set_attributes();
     mlp_f16x3_set_attributes();
     mlp_bwd_f16x3_set_attributes();
+    mlp_f16_2t_set_attributes();
     *out = c;
     return 0;
 }

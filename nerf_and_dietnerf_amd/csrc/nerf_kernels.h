@@ -98,6 +98,10 @@ void mlp_f16x3_set_attributes();
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
 void pack_weights_f16(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
 
+// mlp_f16_2t.hip -- single-pass fp16 render kernel with two 32-sample tiles per wave (same hi-only stream / constants)
+void launch_mlp_f16_2t(const MlpArgs& a, int num_cus, hipStream_t stream);
+void mlp_f16_2t_set_attributes();
+
 // mlp_bwd_f16x3.hip -- the trainer's fused data-gradient chain (the stash forward's counterpart)
 constexpr size_t kBwdStreamBytes = size_t(65) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles
 constexpr int kBwdXyzLd = 64;                                      // floats per row of an encoding-gradient buffer
