@@ -343,7 +343,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     g9[n * 8 + g * 4 + e] = v;
                     mt = fmaxf(mt, fabsf(v));
                 }
-                *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * 128 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
+                *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
             }
         }
         mt = max_with_other_half(mt);
@@ -379,7 +379,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             nl[8] = frag4{pack_h2(l0, 0.f), 0u, 0u, 0u};
         }
 
-        const long long off256 = m * 256 + 4 * h;
+        const long long off256 = m * a.ld + 4 * h;
         float* d_prev = nullptr;
         float* d_cur = a.d_ptr[7] + off256;
         float* dxa = DX ? a.dx_ptr[0] + m * kBwdXyzLd + 4 * h : nullptr;

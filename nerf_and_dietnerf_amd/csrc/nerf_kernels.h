@@ -115,6 +115,7 @@ struct MlpBwdArgs {
     unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k)
     long long Mp;            // rows, multiple of 128
     float alpha;
+    int ld, ld9;             // row pitch (floats) of d_ptr[0..7] / d_ptr[8]
 };
 // single_pass: hi*hi products only, gradients rounded to fp16 between layers (the mixed_float16 policy's backward)
 void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream);

@@ -58,6 +58,9 @@ struct TrainState {
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
+    // row pitch (floats) of the 256-wide / 128-wide activation and gradient buffers (NERF_TRAIN_LDH: padding them off
+    // the power of two was tried against L2-channel hot-spotting of the one-row-per-lane stores and LOST, see train_begin)
+    int ldh = 256, ldh9 = 128;
     bool acc_grads = false;         // the running backward pass ADDS to the gradient blobs (nerf_train_render_gradients)
     // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients
     // and the dynamic loss scale of Keras' LossScaleOptimizer
@@ -192,8 +195,9 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     r |= ensure(c, p.C4, d.Mp * kLdC4 * f);
     r |= ensure(c, p.C8, d.Mp * kLdC8 * f);
     DevBuf* hs[] = {&p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7};
-    for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * 256 * f);
-    r |= ensure(c, p.H9, d.Mp * 128 * f);
+    const int ldh = c->train ? c->train->ldh : 256, ldh9 = c->train ? c->train->ldh9 : 128;
+    for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * ldh * f);
+    r |= ensure(c, p.H9, d.Mp * ldh9 * f);
     if (c->cfg.n_angles == 0) r |= ensure(c, p.H8b, d.Mp * 256 * f);
     r |= ensure(c, p.raw, d.Mp * 4 * f);
     r |= ensure(c, p.T, d.M * f);
@@ -202,8 +206,8 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     r |= ensure(c, p.z, d.M * f);
     if (c->train && c->train->fused_backward && c->train->training) {
         r |= ensure(c, p.masks, (size_t)9 * d.Mp * 32);
-        for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * 256 * f);
-        r |= ensure(c, p.D[8], d.Mp * 128 * f);
+        for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * ldh * f);
+        r |= ensure(c, p.D[8], d.Mp * ldh9 * f);
         r |= ensure(c, p.dxa, d.Mp * kBwdXyzLd * f);
         r |= ensure(c, p.dxb, d.Mp * kBwdXyzLd * f);
     }
@@ -259,7 +263,7 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
         a.M = d.M; a.S = d.S; a.mode = 0; a.alpha = c->cfg.leaky_relu_alpha;
         float* dst[9] = {(float*)p.H1.p, (float*)p.H2.p, (float*)p.H3.p, (float*)p.C4.p, (float*)p.H5.p,
                          (float*)p.H6.p, (float*)p.H7.p, (float*)p.C8.p, (float*)p.H9.p};
-        const int ld[9] = {256, 256, 256, kLdC4, 256, 256, 256, kLdC8, 128};
+        const int ld[9] = {t->ldh, t->ldh, t->ldh, kLdC4, t->ldh, t->ldh, t->ldh, kLdC8, t->ldh9};
         for (int i = 0; i < 9; ++i) {
             a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i];
             a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
@@ -351,23 +355,25 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         // layer; every D_l is written once for the weight-gradient GEMMs below, with max|D_l| in the same gmax slots
         MlpBwdArgs b{};
         b.wstream = n.bstream; b.wconst = n.fcst; b.graw = Graw; b.gmax = gm; b.Mp = Mp; b.alpha = c->cfg.leaky_relu_alpha;
+        b.ld = t->ldh; b.ld9 = t->ldh9;
+        const int ldh = t->ldh, ldh9 = t->ldh9;
         for (int l = 0; l < 9; ++l) {
             b.mask_ptr[l] = (const uint32_t*)p.masks.p + (size_t)l * Mp * 8;
             b.d_ptr[l] = (float*)p.D[l].p;
         }
         b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
         launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream);
-        wgrad(c, t, n, 9, H9, 128, Graw, 4, 4, 0, Mp);
+        wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-        wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], 128, 128, 0, Mp, GM(0));
-        wgrad(c, t, n, 7, H7, 256, b.d_ptr[7], 256, 256, 0, Mp, GM(1));
-        wgrad(c, t, n, 6, H6, 256, b.d_ptr[6], 256, 256, 0, Mp, GM(2));
-        wgrad(c, t, n, 5, H5, 256, b.d_ptr[5], 256, 256, 0, Mp, GM(3));
-        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], 256, 256, 0, Mp, GM(4));
-        wgrad(c, t, n, 3, H3, 256, b.d_ptr[3], 256, 256, 0, Mp, GM(5));
-        wgrad(c, t, n, 2, H2, 256, b.d_ptr[2], 256, 256, 0, Mp, GM(6));
-        wgrad(c, t, n, 1, H1, 256, b.d_ptr[1], 256, 256, 0, Mp, GM(7));
-        wgrad(c, t, n, 0, C4 + 256, kLdC4, b.d_ptr[0], 256, 256, 0, Mp, GM(8));
+        wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0));
+        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(1));
+        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(2));
+        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(3));
+        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(4));
+        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5));
+        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6));
+        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7));
+        wgrad(c, t, n, 0, C4 + 256, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
             launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
@@ -784,6 +790,16 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // for the layer-by-layer GEMMs; it reads the forward's mask records, so it needs the fused forward
     const char* bw = getenv("NERF_TRAIN_BACKWARD");
     t->fused_backward = t->fused_forward && t->dgrad_f16 && !(bw && strcmp(bw, "layers") == 0);
+    t->ldh = 256; t->ldh9 = 128;
+    if (t->fused_forward && t->fused_backward) {
+        // measured (tools/train_bench.py, one device): pitch 256 -> 11.75 ms/step, 264 -> 12.75, 272 -> 12.88, 288 -> 11.95:
+        // rows that are not 128-B aligned cost more than any channel spreading gains, and line-aligned padding gains
+        // nothing -- the power-of-two pitch stays; the knob is kept for re-measuring on other devices
+        const char* lp = getenv("NERF_TRAIN_LDH");
+        t->ldh = lp ? atoi(lp) : 256;
+        if (t->ldh < 256 || t->ldh % 4) t->ldh = 256;
+        t->ldh9 = t->ldh == 256 ? 128 : 136;
+    }
     if (t->mixed && !(t->fused_forward && t->fused_backward)) {
         train_free(c);
         return fail("mixed_float16 training runs on the fused forward / backward kernels: unset NERF_TRAIN_FORWARD / "
