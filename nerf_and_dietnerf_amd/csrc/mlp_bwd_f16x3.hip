@@ -29,20 +29,33 @@
 
 namespace nerf {
 
-// ---- stream geometry: bodies in execution order, each padded to whole 32-quad chunks ----
+// ---- ring geometry.  This kernel (like the stash forward) also STORES 8.5 KB per sample row, and gfx9 counts loads and
+// stores on one vmcnt, so the chunk synchronisation bounds how long a store may stay unacknowledged.  A finer ring
+// (NERF_BWD_CQ=16: 16 KiB chunks in 8 slots, 20 operations of slack instead of 8) was built to widen that window and
+// measured 1.7 % SLOWER per training step (12.05 vs 11.84 ms): the window is not what bounds the stores
+// (L2 bandwidth shared with the weight stream is).  The render kernels' 32 KiB x 4 stays.
+#ifndef NERF_BWD_CQ
+#define NERF_BWD_CQ 32
+#endif
+constexpr int kBCQ = NERF_BWD_CQ;               // quads per chunk
+constexpr int kBRing = kRingBytes / (kBCQ * kQuadBytes);
+constexpr int kBChunkBytes = kBCQ * kQuadBytes;
+static_assert(kBRing * kBChunkBytes == kRingBytes && (kBRing & (kBRing - 1)) == 0, "ring must fill the LDS carve");
+
+// ---- stream geometry: bodies in execution order, each padded to whole chunks ----
 constexpr int kBStepsHead = 9;                 // 128 features of G9 (8 k-steps) + 1 k-step carrying d_sigma
-constexpr int kBChunksHead = (8 * 2 * kBStepsHead + kHCQ - 1) / kHCQ;     // 144 quads -> 5
-constexpr int kBChunksHid = (8 * 2 * 16) / kHCQ;                          // 8
-constexpr int kBChunksHidX = ((8 + 2) * 2 * 16) / kHCQ;                   // 10: layer 4 with its two encoding tiles
-constexpr int kBChunksXyz = (2 * 2 * 16) / kHCQ;                          // 2: layer 0's encoding rows
+constexpr int kBChunksHead = (8 * 2 * kBStepsHead + kBCQ - 1) / kBCQ;     // 144 quads -> 5
+constexpr int kBChunksHid = (8 * 2 * 16) / kBCQ;                          // 8
+constexpr int kBChunksHidX = ((8 + 2) * 2 * 16) / kBCQ;                   // 10: layer 4 with its two encoding tiles
+constexpr int kBChunksXyz = (2 * 2 * 16) / kBCQ;                          // 2: layer 0's encoding rows
 constexpr int kBStreamChunks = kBChunksHead + 7 * kBChunksHid;                                  // 61
 constexpr int kBStreamChunksDx = kBChunksHead + 6 * kBChunksHid + kBChunksHidX + kBChunksXyz;   // 65
-static_assert((size_t)kBStreamChunksDx * kHChunkBytes == kBwdStreamBytes, "backward stream size mismatch");
+static_assert((size_t)kBStreamChunksDx * kBChunkBytes <= kBwdStreamBytes, "backward stream does not fit its buffer");
 // single-pass variant (mixed_float16 policy): hi fragments only, one quad per k-step
-constexpr int kBFChunksHead = (8 * kBStepsHead + kHCQ - 1) / kHCQ;        // 72 quads -> 3
-constexpr int kBFChunksHid = (8 * 16) / kHCQ;                             // 4
-constexpr int kBFChunksHidX = ((8 + 2) * 16) / kHCQ;                      // 5
-constexpr int kBFChunksXyz = (2 * 16) / kHCQ;                             // 1
+constexpr int kBFChunksHead = (8 * kBStepsHead + kBCQ - 1) / kBCQ;        // 72 quads -> 3
+constexpr int kBFChunksHid = (8 * 16) / kBCQ;                             // 4
+constexpr int kBFChunksHidX = ((8 + 2) * 16) / kBCQ;                      // 5
+constexpr int kBFChunksXyz = (2 * 16) / kBCQ;                             // 1
 constexpr int kBFStreamChunks = kBFChunksHead + 7 * kBFChunksHid;                                   // 31
 constexpr int kBFStreamChunksDx = kBFChunksHead + 6 * kBFChunksHid + kBFChunksHidX + kBFChunksXyz;   // 33
 
@@ -105,11 +118,11 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     f32x4 pf[kPf];
     const int ck0 = p.ck;
     uint32_t rdbase[2];
-    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kHRing - 1)) * kHChunkBytes;
-    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kHRing - 1)) * kHChunkBytes;
+    rdbase[0] = lane16 + (uint32_t)((ck0 + 0) & (kBRing - 1)) * kBChunkBytes;
+    rdbase[1] = lane16 + (uint32_t)((ck0 + 1) & (kBRing - 1)) * kBChunkBytes;
     auto issue_read = [&](auto qc) {
         constexpr int Qa = decltype(qc)::value;
-        lds_read_frag_asm<(Qa % kHCQ) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kHCQ) & 1]);
+        lds_read_frag_asm<(Qa % kBCQ) * kQuadBytes>(pf[Qa % kPf], rdbase[(Qa / kBCQ) & 1]);
     };
     static_for<0, kPf>([&](auto ic) {
         if constexpr (decltype(ic)::value < NQ) issue_read(ic);
@@ -177,23 +190,23 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             static_for<0, TPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int Q = u * QPU + TPS * n + t;
-                constexpr int qc = Q % kHCQ;
+                constexpr int qc = Q % kBCQ;
                 if constexpr (qc == 0 && Q > 0) p.ck += 1;
-                if constexpr (qc == kHCQ / 2) {
+                if constexpr (qc == kBCQ / 2) {
                     constexpr int room = (NQ - 1 - Q) / 2;
-                    pipe_sync_c<kHCQ, kHRing, (room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4)>(p);
+                    pipe_sync_c<kBCQ, kBRing, (room + 1 < kBCQ / 4 ? room + 1 : kBCQ / 4)>(p);
                 }
-                if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) {
-                    constexpr int Qs = Q - (qc - kHCQ / 2);
-                    constexpr bool tail = (NQ - 1 - Qs) / 2 + 1 < kHCQ / 4;
-                    pipe_piece_c<(qc - kHCQ / 2) / 2, tail>(p);
+                if constexpr (qc > kBCQ / 2 && (qc - kBCQ / 2) % 2 == 0) {
+                    constexpr int Qs = Q - (qc - kBCQ / 2);
+                    constexpr bool tail = (NQ - 1 - Qs) / 2 + 1 < kBCQ / 4;
+                    pipe_piece_c<(qc - kBCQ / 2) / 2, tail>(p);
                 }
                 lds_wait_frag_asm<(NQ - Q >= kPf ? kPf - 1 : NQ - Q - 1)>(pf[Q % kPf]);
                 araw[t] = pf[Q % kPf];
                 if constexpr (Q + kPf < NQ) {
                     constexpr int Qn = Q + kPf;
-                    if constexpr (Qn % kHCQ == 0)
-                        rdbase[(Qn / kHCQ) & 1] = lane16 + (uint32_t)((ck0 + Qn / kHCQ) & (kHRing - 1)) * kHChunkBytes;
+                    if constexpr (Qn % kBCQ == 0)
+                        rdbase[(Qn / kBCQ) & 1] = lane16 + (uint32_t)((ck0 + Qn / kBCQ) & (kBRing - 1)) * kBChunkBytes;
                     issue_read(std::integral_constant<int, Qn>{});
                 }
             });
@@ -267,7 +280,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             xyz_reg(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
         });
     }
-    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1>(p);
+    if constexpr (NQ % kBCQ != 0 && NQ % kBCQ <= kBCQ / 2) pipe_sync_c<kBCQ, kBRing, 1>(p);
     p.ck += 1;
 }
 
@@ -294,18 +307,18 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     p.src_next = 0;
     p.n_chunks = FAST ? (DX ? kBFStreamChunksDx : kBFStreamChunks) : (DX ? kBStreamChunksDx : kBStreamChunks);
     p.wbase = reinterpret_cast<const char*>(a.wstream);
-    p.voff = wave * (kHCQ / 4 * kQuadBytes) + lane * 16;
-    p.wave_lds = wave * (kHCQ / 4 * kQuadBytes);
+    p.voff = wave * (kBCQ / 4 * kQuadBytes) + lane * 16;
+    p.wave_lds = wave * (kBCQ / 4 * kQuadBytes);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < kHRing - 1; ++c) {
-        p.cur_src = p.wbase + (size_t)p.src_next * kHChunkBytes;
-        p.cur_dst = kLdsRing + c * kHChunkBytes + p.wave_lds;
+    for (int c = 0; c < kBRing - 1; ++c) {
+        p.cur_src = p.wbase + (size_t)p.src_next * kBChunkBytes;
+        p.cur_dst = kLdsRing + c * kBChunkBytes + p.wave_lds;
         p.src_next += 1;
 #pragma unroll
-        for (int q = 0; q < kHCQ / 4; ++q) dma_piece(p.cur_src, p.voff + q * kQuadBytes, p.cur_dst + q * kQuadBytes);
+        for (int q = 0; q < kBCQ / 4; ++q) dma_piece(p.cur_src, p.voff + q * kQuadBytes, p.cur_dst + q * kQuadBytes);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHCQ / 4) * (kHRing - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBCQ / 4) * (kBRing - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -473,7 +486,7 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
     size_t chunk = 0;
     // one body: NU tiles x NSTEP k-steps; src(u, i, n, e, h) gives the blob index of A[i][k] or -1
     auto emit = [&](int NU, int NSTEP, auto src) {
-        const long long b0 = (long long)chunk * (kHChunkBytes / 2);
+        const long long b0 = (long long)chunk * (kBChunkBytes / 2);
         for (int u = 0; u < NU; ++u)
             for (int n = 0; n < NSTEP; ++n)
                 for (int lane = 0; lane < 64; ++lane)
@@ -488,7 +501,7 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
                         idx[b0 + (q + 0) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1));
                         idx[b0 + (q + 1) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1) + 1);
                     }
-        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kHCQ - 1) / kHCQ;
+        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kBCQ - 1) / kBCQ;
     };
     // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step)
     emit(8, kBStepsHead, [&](int u, int i, int n, int e, int h) -> long long {
