@@ -144,10 +144,20 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         constexpr int r = decltype(rc)::value;
         const float v = acc_v * mask_factor<(ht & 1) * 16 + r>(mk[ht >> 1], alpha);
         const float t = v * inv_s;
-        if constexpr ((r & 3) == 0) q0 = t;
-        else if constexpr ((r & 3) == 1) q1 = t;
-        else if constexpr ((r & 3) == 2) q2 = t;
-        else store4(dst, 32 * ht, r, t);
+        if constexpr (FAST) {
+            // mixed_float16 policy: D is stored in fp16 (dst points at fp16 rows).  The values carry the loss scale, as
+            // the policy's activation gradients do: an overflow becomes Inf here, NaN in the weight gradient, and the
+            // LossScaleOptimizer logic skips the step and halves the scale.
+            if constexpr ((r & 1) == 0) q0 = t;
+            else if constexpr ((r & 3) == 1) q1 = __uint_as_float(pack_h2(q0, t));
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * ht + 8 * (r >> 2)) =
+                     make_uint2(__float_as_uint(q1), pack_h2(q0, t));
+        } else {
+            if constexpr ((r & 3) == 0) q0 = t;
+            else if constexpr ((r & 3) == 1) q1 = t;
+            else if constexpr ((r & 3) == 2) q2 = t;
+            else store4(dst, 32 * ht, r, t);
+        }
         const float pk = v * rho_s;
         L.mrun = fmaxf(L.mrun, fabsf(pk));
         if constexpr ((r & 1) == 0) pc = pk;
@@ -356,7 +366,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     g9[n * 8 + g * 4 + e] = v;
                     mt = fmaxf(mt, fabsf(v));
                 }
-                *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
+                if constexpr (FAST)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[8]) + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) =
+                        make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
+                else
+                    *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
             }
         }
         mt = max_with_other_half(mt);
@@ -394,7 +408,12 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
 
         const long long off256 = m * a.ld + 4 * h;
         float* d_prev = nullptr;
-        float* d_cur = a.d_ptr[7] + off256;
+        // (FAST: the D rows are fp16; the pointers stay float* and are advanced in halfs)
+        auto d_row = [&](int l) -> float* {
+            if constexpr (FAST) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.d_ptr[l]) + off256);
+            else return a.d_ptr[l] + off256;
+        };
+        float* d_cur = d_row(7);
         float* dxa = DX ? a.dx_ptr[0] + m * kBwdXyzLd + 4 * h : nullptr;
         float* dxb = DX ? a.dx_ptr[1] + m * kBwdXyzLd + 4 * h : nullptr;
         frag4 mk_prev = mq[1], mk_cur = mq[1];
@@ -410,7 +429,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             for (int i = 1; i < 8; ++i) mq[i] = mq[i + 1];
             mk_cur = mq[1];
             d_prev = d_cur;
-            d_cur = a.d_ptr[l - 1] + off256;
+            d_cur = d_row(l - 1);
             const int gslot_prev = 8 - l;          // slot k <-> D_(8-k)
             if (DX && l == 4)
                 bwd_body<BW_HID, DX ? 2 : 0, true, FAST>(p, lane16, alpha, L, true, d_prev, d_cur, dxa, mk_prev, mk_cur,
@@ -437,7 +456,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     o[e] = v;
                     tmax = fmaxf(tmax, fabsf(v));
                 }
-                *reinterpret_cast<f32x4*>(d_cur + 32 * 7 + 8 * (r >> 2)) = o;
+                if constexpr (FAST)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * 7 + 8 * (r >> 2)) =
+                        make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
+                else
+                    *reinterpret_cast<f32x4*>(d_cur + 32 * 7 + 8 * (r >> 2)) = o;
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);

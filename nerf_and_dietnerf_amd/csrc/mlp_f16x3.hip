@@ -34,6 +34,8 @@ __device__ unsigned long long g_stamps_h[16];
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
 // STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
 // of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store.
+// FAST + STASH (the mixed_float16 policy's forward) writes the stash in fp16 -- the very dwords it packs as the next
+// layer's operand, four consecutive features per 8-byte store -- and st_prev / st_cur then point at fp16 rows.
 // It also records the LeakyReLU' masks the fused backward (mlp_bwd_f16x3.hip) multiplies by: one bit per activation
 // (1 = positive), bit 16 ut + r of the lane's 128-bit word mk_cur = accumulator register r of output tile ut, i.e.
 // exactly the layout in which the backward's accumulators hold the gradient of that activation; one 16-byte store
@@ -111,12 +113,21 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             *reinterpret_cast<f32x4*>(base + 32 * ut + 8 * (r >> 2)) = v;
         }
     };
+    uint32_t sqh = 0u;               // fp16 stash: the first packed pair of the four features being collected
+    (void)sqh;
+    auto stash4h = [&](auto utc, auto rc, uint32_t ph, float* base) {
+        constexpr int ut = decltype(utc)::value;
+        constexpr int r = decltype(rc)::value;
+        if constexpr ((r & 3) == 0) sqh = ph;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * ut + 8 * (r >> 2)) = make_uint2(sqh, ph);
+    };
     auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel, auto pend_sel) {
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         constexpr int n = 2 * ut + (r >> 3), e = r & 7;
         if constexpr (STASH) {
-            stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
+            if constexpr (FAST) stash4h(utc, rc, pack_h2(y0, y1), decltype(pend_sel)::value ? st_prev : st_cur);
+            else stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
             constexpr int sh = (ut & 1) * 16 + r;
             const uint32_t bits = (y0 > 0.f ? (1u << sh) : 0u) | (y1 > 0.f ? (2u << sh) : 0u);
             if constexpr (decltype(pend_sel)::value) mk_prev[ut >> 1] |= bits;
@@ -215,6 +226,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                     xc[et * 16 + n] = y;
                     if constexpr (STASH) {      // layer 8's outputs (128 features) go to the stash in fours as well
                         if constexpr ((n & 1) == 0) ycarry = y;
+                        else if constexpr (FAST) stash4h(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, pack_h2(ycarry, y), st_cur);
                         else stash4(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, st_cur);
                         mk_cur[et >> 1] |= y > 0.f ? (1u << ((et & 1) * 16 + n)) : 0u;
                     }
@@ -389,7 +401,14 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
         // stash rows of this lane's sample (rows beyond M exist: the buffers are padded to whole 128-row tiles)
         auto st_of = [&](int l) -> float* {
             if constexpr (!STASH) return nullptr;
-            else return a.st_ptr[l] + (a.diag_wrap ? (long long)(blockIdx.x * 8 + (j & 7)) : tile * 128 + wave * 32 + j) * (long long)a.st_ld[l] + 4 * h;
+            else {
+                // row offset in elements (st_ld[l] elements per row): fp32 elements, or fp16 ones under FAST (the pointer
+                // arithmetic below is in floats, so halve it there)
+                const long long row = a.diag_wrap ? (long long)(blockIdx.x * 8 + (j & 7)) : tile * 128 + wave * 32 + j;
+                const long long off = row * (long long)a.st_ld[l] + 4 * h;
+                if constexpr (FAST) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.st_ptr[l]) + off);
+                else return a.st_ptr[l] + off;
+            }
         };
         auto mk_of = [&](int l) -> frag4* {
             if constexpr (!STASH) return nullptr;

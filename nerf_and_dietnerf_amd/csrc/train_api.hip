@@ -191,13 +191,16 @@ struct PassDims { long long N; int S; long long M, Mp; };
 
 int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     const size_t f = sizeof(float);
+    // the mixed_float16 policy keeps activations and pre-activation gradients in fp16 (same element pitches); sized for
+    // fp32 anyway: the buffers are shared with later fp32-policy trainers of the same context only after train_free
+    const size_t ea = c->train && c->train->mixed && c->train->training ? 2 : f;
     int r = 0;
-    r |= ensure(c, p.C4, d.Mp * kLdC4 * f);
-    r |= ensure(c, p.C8, d.Mp * kLdC8 * f);
+    r |= ensure(c, p.C4, d.Mp * kLdC4 * ea);
+    r |= ensure(c, p.C8, d.Mp * kLdC8 * ea);
     DevBuf* hs[] = {&p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7};
     const int ldh = c->train ? c->train->ldh : 256, ldh9 = c->train ? c->train->ldh9 : 128;
-    for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * ldh * f);
-    r |= ensure(c, p.H9, d.Mp * ldh9 * f);
+    for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * ldh * ea);
+    r |= ensure(c, p.H9, d.Mp * ldh9 * ea);
     if (c->cfg.n_angles == 0) r |= ensure(c, p.H8b, d.Mp * 256 * f);
     r |= ensure(c, p.raw, d.Mp * 4 * f);
     r |= ensure(c, p.T, d.M * f);
@@ -206,8 +209,8 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     r |= ensure(c, p.z, d.M * f);
     if (c->train && c->train->fused_backward && c->train->training) {
         r |= ensure(c, p.masks, (size_t)9 * d.Mp * 32);
-        for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * ldh * f);
-        r |= ensure(c, p.D[8], d.Mp * ldh9 * f);
+        for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * ldh * ea);
+        r |= ensure(c, p.D[8], d.Mp * ldh9 * ea);
         r |= ensure(c, p.dxa, d.Mp * kBwdXyzLd * f);
         r |= ensure(c, p.dxb, d.Mp * kBwdXyzLd * f);
     }
@@ -253,7 +256,8 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
     TNet& n = t->net[which];
     TPass& p = t->pass[which];
     float *raw = (float*)p.raw.p, *z = (float*)p.z.p;
-    launch_train_encode(o, dirs, z, 0, d.M, d.S, d.Mp, c->cfg.n_angles, 0, (float*)p.C4.p, (float*)p.C8.p, c->stream);
+    launch_train_encode(o, dirs, z, 0, d.M, d.S, d.Mp, c->cfg.n_angles, 0, (float*)p.C4.p, (float*)p.C8.p, c->stream,
+                        t->mixed);
     if (t->fused_forward && n.fstream) {
         // the render path's fused PE + MLP kernel (3-pass split fp16, fp32-class results) with every activation also
         // written to the buffers the backward GEMMs read: 4x the rate of the layer-wise forward
@@ -287,14 +291,16 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
     g.partial = (float*)t->partial.p; g.Kp = L.Kp; g.Nw = Ncols; g.M = Mp;
     // the heads' (K x 4) results come from a VALU kernel that wants many small slabs; the GEMMs use kTrainSplits
-    const bool f16 = t->wgrad_f16 && gmax && Ncols >= 128;
+    const bool f16 = (t->wgrad_f16 && gmax && Ncols >= 128) || (t->mixed && Ncols >= 128);
     const bool wide = f16 && t->wgrad_wide && Ncols >= 256;
+    g.a_f16 = t->mixed ? 1 : 0;
     const int want_splits = Ncols == 4 ? 1024 : wide ? kTrainSplitsWide : kTrainSplits;
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 15) / 16 * 16;
     g.rows_per_split = (int)rps;
     g.gmax = gmax;
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
+    else if (t->mixed) launch_gemm_atb_f16(g, c->stream, wide);
     else if (f16) launch_gemm_atb_h(g, c->stream, wide);
     else launch_gemm_atb(g, c->stream);
     ReduceArgs r{};
@@ -373,7 +379,9 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5));
         wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6));
         wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7));
-        wgrad(c, t, n, 0, C4 + 256, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
+        // (C4 + 256: the xyz encoding's columns -- 256 ELEMENTS in, i.e. half the byte offset under the fp16 policy)
+        const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + 256) : C4 + 256;
+        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
             launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);

@@ -47,12 +47,15 @@ struct GemmAtb {
     float* partial; int Kp; int Nw;     // partial: [splits][Kp + 1][Nw]
     long long M; int rows_per_split;    // multiple of 16
     const unsigned* gmax;               // split-fp16 variant: bits of max|G| (written by G's producer); G is scaled to fp16 range
+    int a_f16;                          // head_wgrad: A holds fp16 elements (lda in halfs); gemm_atb_f16: both operands do
 };
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
 // three MFMA passes, fp32 accumulation; G is pre-scaled by a power of two so that its largest entry sits at 2^14
 void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide = false);   // wide: 256 x 256 tile, 512 threads
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s);   // N = 4 (the heads): VALU kernel, same partial layout
+// mixed_float16 policy: A and G are fp16 rows (lda / ldg in halfs), one MFMA pass, no scaling (G carries the loss scale)
+void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide = false);
 
 // grad[blob layout] = sum over splits of partial (deterministic order)
 struct ReduceArgs {
@@ -74,7 +77,8 @@ void launch_relayout(const RelayoutArgs& a, hipStream_t s);
 
 // rows [row0, row0 + M) of the sample grid (rays x S, or xyz/view rows in xyz_mode) -> local rows 0..M of C4/C8
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
-                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s);
+                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s,
+                         bool half_out = false);   // half_out: C4 / C8 are fp16 rows of the same element pitch
 void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
                 hipStream_t s);
 void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, float inv_scale, int* all_finite, hipStream_t s);

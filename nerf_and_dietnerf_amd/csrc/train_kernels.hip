@@ -538,6 +538,163 @@ void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_atb_f16: the weight-gradient GEMM of the mixed_float16 policy.  A (activations) and G (loss-scaled pre-activation
+// gradients) arrive as fp16 rows from the single-pass stash forward / backward chain: half the bytes of the fp32 buffers
+// (this GEMM is bound by reading them), no hi/lo split and no conversion while staging -- a 4 x 4 block of halfs is
+// transposed with byte permutes -- and ONE v_mfma_f32_32x32x16_f16 pass per product, fp32 accumulation.  Same tiling,
+// LDS layout ([plane][column][16 rows], 48-byte column stride), partial-sum layout and bias row as gemm_atb_h.  A
+// gradient that left the fp16 range arrives as Inf and makes the partial sums non-finite: the loss-scale logic skips
+// that step (src/NeRF.py:159-163 under LossScaleOptimizer).
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_f16_kernel(const GemmAtb g) {
+    constexpr int kPl = W * kHColStride;
+    constexpr int WNW = W / 64;
+    constexpr int KTL = W / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kPl];    // planes: A, G
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave / WNW, wn = wave % WNW;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kt_n = (g.Kp + W - 1) / W, nt_n = (g.Nw + W - 1) / W, T = kt_n * nt_n;
+    const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
+    int split = grp * 8 + rem % 8, tile = rem / 8;
+    if (grp * 8 + 8 > n_splits) {
+        const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
+        split = grp * 8 + r2 % left;
+        tile = r2 / left;
+    }
+    const int kb = (tile % kt_n) * W, nb = (tile / kt_n) * W;
+    const bool first_ktile = tile % kt_n == 0;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    const bool isG = t >= W;
+    const int b = t & (W - 1), rg = b & 3, cg = b >> 2;
+    const int ld = isG ? g.ldg : g.lda;
+    const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) + (isG ? nb : kb) + (ms + 4 * rg) * ld + 4 * cg;
+    const int wbase = (isG ? 1 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
+
+    f32x16 acc[KTL][2];
+#pragma unroll
+    for (int a = 0; a < KTL; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+
+    // Four register stages of operand rows: one workgroup per CU and only 8 MFMAs per wave and 16-row step mean a step
+    // lasts a few hundred cycles, far less than a global load's latency -- with the one-deep prefetch of gemm_atb_h this
+    // kernel ran at the speed of that latency (2.5 TB/s).  Loads are issued three steps ahead of their use instead.
+    constexpr int NS = 4;
+    uint2 R[NS][4];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R[q][e] = make_uint2(0u, 0u);
+    auto h2f = [](uint32_t w, int hi) -> float {
+        const h2v v = __builtin_bit_cast(h2v, w);
+        return (float)v[hi];
+    };
+    auto fetch = [&](uint2 (&r)[4], long long st) {
+        if (on) {
+            const uint16_t* q_ = src + (size_t)st * 16 * ld;
+            r[0] = *reinterpret_cast<const uint2*>(q_);
+            r[1] = *reinterpret_cast<const uint2*>(q_ + ld);
+            r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)ld);
+            r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)ld);
+        }
+    };
+    // column j of the 4 x 4 block = halfs (r0, r1, r2, r3)[j]: two byte permutes per column
+    auto park = [&](const uint2 (&r)[4], int buf) {
+        if (isG && first_ktile) {
+            cs0 += (h2f(r[0].x, 0) + h2f(r[1].x, 0)) + (h2f(r[2].x, 0) + h2f(r[3].x, 0));
+            cs1 += (h2f(r[0].x, 1) + h2f(r[1].x, 1)) + (h2f(r[2].x, 1) + h2f(r[3].x, 1));
+            cs2 += (h2f(r[0].y, 0) + h2f(r[1].y, 0)) + (h2f(r[2].y, 0) + h2f(r[3].y, 0));
+            cs3 += (h2f(r[0].y, 1) + h2f(r[1].y, 1)) + (h2f(r[2].y, 1) + h2f(r[3].y, 1));
+        }
+        unsigned char* w_ = &lds[buf][wbase];
+        *reinterpret_cast<uint2*>(w_ + 0 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x05040100u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x05040100u));
+        *reinterpret_cast<uint2*>(w_ + 1 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x07060302u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x07060302u));
+        *reinterpret_cast<uint2*>(w_ + 2 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x05040100u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x05040100u));
+        *reinterpret_cast<uint2*>(w_ + 3 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x07060302u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x07060302u));
+    };
+
+    auto compute = [&](int buf) {
+        const unsigned char* base = lds[buf];
+        h8v ah[KTL], gh[2];
+#pragma unroll
+        for (int q = 0; q < KTL; ++q)
+            ah[q] = *reinterpret_cast<const h8v*>(base + (wk * (W / 2) + q * 32 + li) * kHColStride + 16 * lh);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            gh[q] = *reinterpret_cast<const h8v*>(base + kPl + (wn * 64 + q * 32 + li) * kHColStride + 16 * lh);
+#pragma unroll
+        for (int a = 0; a < KTL; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gh[c], acc[a][c], 0, 0, 0);
+    };
+
+    if (ms < me) {
+        const long long steps = (me - ms) / 16;
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q)
+            if (q < steps) fetch(R[q], q);
+        park(R[0], 0);
+        __syncthreads();
+        int buf = 0;
+        // step st: registers in slot st % NS (fetched NS - 1 iterations ago); unrolled by NS for static register indices
+        for (long long base_st = 1; base_st < steps; base_st += NS) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const long long st = base_st + i;
+                if (st < steps) {
+                    if (st + NS - 2 < steps) fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    park(R[(1 + i) % NS], buf ^ 1);
+                    __syncthreads();
+                    buf ^= 1;
+                }
+            }
+        }
+        compute(buf);
+    }
+
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+#pragma unroll
+    for (int a = 0; a < KTL; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = nb + wn * 64 + c * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + wk * (W / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < g.Kp && n < g.Nw) part[(size_t)k * g.Nw + n] = acc[a][c][r];
+            }
+        }
+    cs0 += __shfl_xor(cs0, 1); cs1 += __shfl_xor(cs1, 1); cs2 += __shfl_xor(cs2, 1); cs3 += __shfl_xor(cs3, 1);
+    cs0 += __shfl_xor(cs0, 2); cs1 += __shfl_xor(cs1, 2); cs2 += __shfl_xor(cs2, 2); cs3 += __shfl_xor(cs3, 2);
+    if (first_ktile && isG && rg == 0 && nb + 4 * cg < g.Nw) {
+        float* prow = part + (size_t)g.Kp * g.Nw + nb + 4 * cg;
+        prow[0] = cs0; prow[1] = cs1; prow[2] = cs2; prow[3] = cs3;
+    }
+}
+
+void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide) {
+    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    if (wide) {
+        const int tiles = ((g.Kp + 255) / 256) * ((g.Nw + 255) / 256);
+        hipLaunchKernelGGL(gemm_atb_f16_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, s, g);
+    } else {
+        const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
+        hipLaunchKernelGGL(gemm_atb_f16_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_abt_h: the data-gradient GEMM  G_prev = (G . W^T [+ rank-1]) * LeakyReLU'(H)  on the fp16 matrix cores, same
 // arithmetic as gemm_atb_h: G is scaled to the fp16 range (its max comes from its producer) and split hi + lo while it is
 // staged (rows are k-contiguous: no transpose), W comes pre-split from the relayout kernel; three passes of
@@ -722,7 +879,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const GemmAtb g) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     gv[q] = *reinterpret_cast<const float4*>(g.G + (m + q) * g.ldg);
-                    av[q] = ones ? 1.0f : g.A[(m + q) * g.lda + k];
+                    av[q] = ones ? 1.0f : g.a_f16 ? (float)reinterpret_cast<const _Float16*>(g.A)[(m + q) * g.lda + k]
+                                                  : g.A[(m + q) * g.lda + k];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -735,8 +893,59 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const GemmAtb g) {
     }
 }
 
+// fp16 activations (mixed_float16 policy): a thread owns two neighbouring columns of A (one 4-byte load per row) and the
+// last thread of the workgroup the column sums of G
+__global__ __launch_bounds__(256) void head_wgrad_f16_kernel(const GemmAtb g) {
+    const int split = blockIdx.x, t = threadIdx.x;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
+    const bool ones = t == 255;                            // (Kp <= 320: the column pairs need at most 160 threads)
+    const int k0 = 2 * t;
+    const bool valid = ones || k0 < g.Kp;
+    const bool live = ones || k0 < g.K;                    // columns beyond K are padding: zeros, but written
+    float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (valid && live)
+        for (long long m = ms; m < me; m += 8) {
+            float av[8][2];
+            float4 gv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                gv[q] = *reinterpret_cast<const float4*>(g.G + (m + q) * g.ldg);
+                if (ones) { av[q][0] = 1.0f; av[q][1] = 0.f; }
+                else {
+                    const h2v v = __builtin_bit_cast(h2v, *reinterpret_cast<const uint32_t*>(A + (m + q) * g.lda + k0));
+                    av[q][0] = (float)v[0]; av[q][1] = (float)v[1];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a[e][0] = fmaf(av[q][e], gv[q].x, a[e][0]); a[e][1] = fmaf(av[q][e], gv[q].y, a[e][1]);
+                    a[e][2] = fmaf(av[q][e], gv[q].z, a[e][2]); a[e][3] = fmaf(av[q][e], gv[q].w, a[e][3]);
+                }
+        }
+    if (ones) {
+        float* o = part + (size_t)g.Kp * g.Nw;
+        o[0] = a[0][0]; o[1] = a[0][1]; o[2] = a[0][2]; o[3] = a[0][3];
+    } else if (valid) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (k0 + e < g.Kp) {
+                float* o = part + (size_t)(k0 + e) * g.Nw;
+                o[0] = a[e][0]; o[1] = a[e][1]; o[2] = a[e][2]; o[3] = a[e][3];
+            }
+    }
+}
+
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s) {
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    if (g.a_f16) {
+        hipLaunchKernelGGL(head_wgrad_f16_kernel, dim3((unsigned)splits), dim3(256), 0, s, g);
+        return;
+    }
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)splits), dim3(256), 0, s, g);
 }
 
@@ -827,17 +1036,18 @@ void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float l
 //   sample_along_rays  src/UtilsCV.py:584-599, get_view_directions :124-143, positional encodings
 //   src/UtilsNeuralRadianceField.py:52-85.  Rows >= N*S (padding to 128) get zeros.
 // ------------------------------------------------------------------------------------------------
+template <typename T>      // T = float, or _Float16 for the mixed_float16 policy's half-width activation buffers
 __global__ void train_encode_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                     const float* __restrict__ z, long long row0, long long M, int S, long long Mp,
-                                    int n_angles, int xyz_mode, float* __restrict__ C4, float* __restrict__ C8) {
+                                    int n_angles, int xyz_mode, T* __restrict__ C4, T* __restrict__ C8) {
     // local row m of this chunk = global sample row row0 + m; xyz_mode: o = xyz (M,3), d = view_dirs (M,3) or null
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mp) return;
-    float* ex = C4 + m * kLdC4 + 256;
-    float* ed = C8 + m * kLdC8 + 256;
+    T* ex = C4 + m * kLdC4 + 256;
+    T* ed = C8 + m * kLdC8 + 256;
     if (m >= M) {
-        for (int i = 0; i < kXyzPad; ++i) ex[i] = 0.f;
-        for (int i = 0; i < kDirPad; ++i) ed[i] = 0.f;
+        for (int i = 0; i < kXyzPad; ++i) ex[i] = (T)0.f;
+        for (int i = 0; i < kDirPad; ++i) ed[i] = (T)0.f;
         return;
     }
     const long long gm = row0 + m;
@@ -856,30 +1066,35 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
         v3[0] = dd.x; v3[1] = dd.y; v3[2] = dd.z;
     }
     for (int c = 0; c < 3; ++c) {
-        ex[c * 11] = p[c];
+        ex[c * 11] = (T)p[c];
         for (int k = 0; k < 5; ++k) {
             const float th = __fmul_rn(p[c], kPi * (float)(1 << k));
-            ex[c * 11 + 1 + 2 * k] = sin_shifted(th, 0);
-            ex[c * 11 + 2 + 2 * k] = sin_shifted(th, 1);
+            ex[c * 11 + 1 + 2 * k] = (T)sin_shifted(th, 0);
+            ex[c * 11 + 2 + 2 * k] = (T)sin_shifted(th, 1);
         }
     }
-    for (int i = 33; i < kXyzPad; ++i) ex[i] = 0.f;
+    for (int i = 33; i < kXyzPad; ++i) ex[i] = (T)0.f;
     const int ncomp = n_angles > 0 ? n_angles + 1 : 0;     // the xyz-only network has no direction input
     for (int c = 0; c < ncomp; ++c) {
         const float v = n_angles == 2 ? v3[c] : (c == 0 ? v3[0] : v3[2]);
         for (int k = 0; k < 4; ++k) {
             const float th = __fmul_rn(v, kPi * (float)(1 << k));
-            ed[c * 8 + 2 * k] = sin_shifted(th, 0);
-            ed[c * 8 + 2 * k + 1] = sin_shifted(th, 1);
+            ed[c * 8 + 2 * k] = (T)sin_shifted(th, 0);
+            ed[c * 8 + 2 * k + 1] = (T)sin_shifted(th, 1);
         }
     }
-    for (int i = ncomp * 8; i < kDirPad; ++i) ed[i] = 0.f;
+    for (int i = ncomp * 8; i < kDirPad; ++i) ed[i] = (T)0.f;
 }
 
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
-                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s) {
-    hipLaunchKernelGGL(train_encode_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, o, d, z, row0, M, S, Mp,
-                       n_angles, xyz_mode, C4, C8);
+                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s, bool half_out) {
+    if (Mp <= 0) return;
+    const dim3 grid((unsigned)((Mp + 255) / 256)), block(256);
+    if (half_out)
+        hipLaunchKernelGGL(train_encode_kernel<_Float16>, grid, block, 0, s, o, d, z, row0, M, S, Mp, n_angles, xyz_mode,
+                           reinterpret_cast<_Float16*>(C4), reinterpret_cast<_Float16*>(C8));
+    else
+        hipLaunchKernelGGL(train_encode_kernel<float>, grid, block, 0, s, o, d, z, row0, M, S, Mp, n_angles, xyz_mode, C4, C8);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -459,7 +459,9 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
       * gradients: fp16-class agreement with the float64 autograd oracle on the smooth alpha = 1 network (fine: 2e-2 of
         max|g|, cosine > 0.9999; coarse, through the sampler: cosine > 0.999 -- the fp32 policy reaches 1e-5..1e-4 on
         the same problem), loss within 1e-3 relative;
-      * the loss scale is a pure power-of-two factor on the backward pass: the unscaled gradients do not depend on it;
+      * activations and pre-activation gradients live in fp16 (half the bytes of the fp32 policy's buffers), the latter
+        carrying the loss scale as the policy's activation gradients do; two sane scales give the same gradients to fp16
+        class;
       * dynamic scaling: `dynamic_growth_steps` finite steps double the scale; a batch with a non-finite target makes the
         gradients non-finite -> that step is SKIPPED (weights unchanged) and the scale halves."""
     from oracle import train_oracle as T
@@ -467,7 +469,7 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
     r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
                           sampler_grad=True, alpha=1.0)
     grads = {}
-    for scale in (32768.0, 8.0):
+    for scale in (32768.0, 4096.0):
         ctx = _ctx(p, leaky_relu_alpha=1.0)
         ctx.train_begin(5e-4, mixed_float16=True, initial_loss_scale=scale)
         m, gc, gf = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
@@ -483,8 +485,10 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
         # sampler term, whose inverse-CDF interpolation has gains of 1e5 (its 1e-5 clamp) on fp16-class weights
         assert ef <= 2e-2 and cf > 0.9999 and ec <= 2e-1 and cc > 0.999
         ctx.close()
-    np.testing.assert_allclose(grads[32768.0][1], grads[8.0][1], rtol=0, atol=1e-6 * np.abs(grads[8.0][1]).max())
-    np.testing.assert_allclose(grads[32768.0][0], grads[8.0][0], rtol=0, atol=1e-6 * np.abs(grads[8.0][0]).max())
+    # a power-of-two loss scale changes nothing but which gradient entries leave fp16's normal range in the half-width
+    # buffers: between two sane scales the unscaled gradients agree to fp16 class
+    np.testing.assert_allclose(grads[32768.0][1], grads[4096.0][1], rtol=0, atol=2e-2 * np.abs(grads[4096.0][1]).max())
+    assert _cos(grads[32768.0][0], grads[4096.0][0].astype(np.float64)) > 0.999
     # dynamics
     ctx = _ctx(p)
     ctx.train_begin(5e-4, mixed_float16=True, initial_loss_scale=1024.0, dynamic_growth_steps=3)

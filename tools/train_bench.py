@@ -1,5 +1,6 @@
 """Times NeRF.train_step at the reference's batch (4096 rays, 64 coarse + 128 fine) with device-resident
-inputs; prints ms/step and rays/s.  Usage: python tools/train_bench.py [steps] [n_rays]"""
+inputs; prints ms/step and rays/s.  Usage: python tools/train_bench.py [steps] [n_rays] [mixed]
+(a third argument "mixed" selects the loss-scaled mixed_float16 policy)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +12,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ctx = N.Context(near=2.0 / 3, far=5.0 / 3)
 ctx.load_weights(0, N.glorot_blob(0)); ctx.load_weights(1, N.glorot_blob(1))
 ctx.use_torch_stream()
-ctx.train_begin(5e-4)
+mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"
+ctx.train_begin(5e-4, mixed_float16=mixed)
 g = torch.Generator(device="cuda").manual_seed(0)
 o = torch.zeros((n, 4), device="cuda"); o[:, 2] = 1.0; o[:, 3] = 1.0
 d = torch.randn((n, 4), device="cuda", generator=g) * 0.3; d[:, 2] = -1.0; d[:, 3] = 0.0
@@ -27,4 +29,4 @@ dt = (time.perf_counter() - t0) / steps
 m = ctx.train_step(o, d, tgt, 64, 128, seed=99)
 rows = n * (64 + 128)
 flops = rows * 1024304 * 3
-print(f"train_step: {dt*1e3:.2f} ms/step, {n/dt:.0f} rays/s, {flops/dt/1e12:.1f} TFLOP/s (3x forward GEMM flops), loss {m['loss']:.4f}")
+print(f"train_step ({'mixed_float16' if mixed else 'float32'} policy): {dt*1e3:.2f} ms/step, {n/dt:.0f} rays/s, {flops/dt/1e12:.1f} TFLOP/s (3x forward GEMM flops), loss {m['loss']:.4f}")
