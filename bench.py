@@ -365,9 +365,10 @@ def main():
                  "loss_finite": bool(m_tr["loss"] == m_tr["loss"]),
                  "mixed_float16_policy": {"ms_per_step": e_mx * 1e3, "value": n_tr / e_mx, "unit": "rays/s",
                                           "loss_scale": ls_mx[0], "steps_skipped": ls_mx[2],
-                                          "note": "single-pass fp16 forward + data gradients, dynamic loss scaling "
-                                                  "(src/ExecutionRun.py:220-221, src/NeRF.py:159-163); weight "
-                                                  "gradients stay on split operands"},
+                                          "note": "the reference's production policy (src/ExecutionRun.py:220-221, "
+                                                  "src/NeRF.py:159-163): single-pass fp16 forward, data and weight "
+                                                  "gradients on fp16 activation / gradient buffers, fp32 accumulation "
+                                                  "and master weights, dynamic loss scaling"},
                  "roofline": {"bound": "mfma",
                               "kernel": "whole step: mlp_f16x3_stash_kernel (fused forward) + mlp_bwd_f16x3[_dx]_kernel "
                                         "(fused data-gradient chain) + gemm_atb_h (weight gradients), all 3-pass "

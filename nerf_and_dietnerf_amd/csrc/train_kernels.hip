@@ -432,31 +432,42 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;      // column sums of the raw G block (bias gradient)
 
-    float4 r0 = zero4, r1 = zero4, r2 = zero4, r3 = zero4;
-#define ATBH_FETCH(ST)                                                                        \
-    if (on) {                                                                                 \
-        const float* q_ = src + (size_t)(ST) * 16 * ld;                                       \
-        r0 = *reinterpret_cast<const float4*>(q_);                                            \
-        r1 = *reinterpret_cast<const float4*>(q_ + ld);                                       \
-        r2 = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);                           \
-        r3 = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);                           \
-    }
-#define ATBH_COL(J, C0, C1, C2, C3, BUF)                                                      \
-    {                                                                                         \
-        uint32_t h01, l01, h23, l23;                                                          \
-        split_pack2((C0) * mul, (C1) * mul, h01, l01);                                        \
-        split_pack2((C2) * mul, (C3) * mul, h23, l23);                                        \
-        unsigned char* w_ = &lds[BUF][wbase + (J) * kHColStride];                             \
-        *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);                                 \
-        *reinterpret_cast<uint2*>(w_ + kPl) = make_uint2(l01, l23);                       \
-    }
-#define ATBH_PARK(BUF)                                                                        \
-    cs0 += (r0.x + r1.x) + (r2.x + r3.x); cs1 += (r0.y + r1.y) + (r2.y + r3.y);               \
-    cs2 += (r0.z + r1.z) + (r2.z + r3.z); cs3 += (r0.w + r1.w) + (r2.w + r3.w);               \
-    ATBH_COL(0, r0.x, r1.x, r2.x, r3.x, BUF)                                                  \
-    ATBH_COL(1, r0.y, r1.y, r2.y, r3.y, BUF)                                                  \
-    ATBH_COL(2, r0.z, r1.z, r2.z, r3.z, BUF)                                                  \
-    ATBH_COL(3, r0.w, r1.w, r2.w, r3.w, BUF)
+    // Register stages of operand rows (NERF_ATBH_STAGES, default 3): with one 512-thread workgroup per CU a 16-row step
+    // lasts ~800 cycles, less than a global load's latency; loads are issued NS - 1 steps ahead of their use.
+#ifndef NERF_ATBH_STAGES
+#define NERF_ATBH_STAGES 3
+#endif
+    constexpr int NS = NERF_ATBH_STAGES;
+    float4 R[NS][4];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R[q][e] = zero4;
+    auto fetch = [&](float4 (&r)[4], long long st) {
+        if (on) {
+            const float* q_ = src + (size_t)st * 16 * ld;
+            r[0] = *reinterpret_cast<const float4*>(q_);
+            r[1] = *reinterpret_cast<const float4*>(q_ + ld);
+            r[2] = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);
+            r[3] = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);
+        }
+    };
+    auto col = [&](int jcol, float c0, float c1, float c2, float c3, int buf) {
+        uint32_t h01, l01, h23, l23;
+        split_pack2(c0 * mul, c1 * mul, h01, l01);
+        split_pack2(c2 * mul, c3 * mul, h23, l23);
+        unsigned char* w_ = &lds[buf][wbase + jcol * kHColStride];
+        *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(w_ + kPl) = make_uint2(l01, l23);
+    };
+    auto park = [&](const float4 (&r)[4], int buf) {
+        cs0 += (r[0].x + r[1].x) + (r[2].x + r[3].x); cs1 += (r[0].y + r[1].y) + (r[2].y + r[3].y);
+        cs2 += (r[0].z + r[1].z) + (r[2].z + r[3].z); cs3 += (r[0].w + r[1].w) + (r[2].w + r[3].w);
+        col(0, r[0].x, r[1].x, r[2].x, r[3].x, buf);
+        col(1, r[0].y, r[1].y, r[2].y, r[3].y, buf);
+        col(2, r[0].z, r[1].z, r[2].z, r[3].z, buf);
+        col(3, r[0].w, r[1].w, r[2].w, r[3].w, buf);
+    };
 
     auto compute = [&](int buf) {
         const unsigned char* base = lds[buf];
@@ -485,24 +496,30 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
 
     if (ms < me) {
         const long long steps = (me - ms) / 16;
-        ATBH_FETCH(0)
-        ATBH_PARK(0)
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q)
+            if (q < steps) fetch(R[q], q);
+        park(R[0], 0);
         __syncthreads();
         int buf = 0;
-        for (long long st = 1; st < steps; ++st) {
-            ATBH_FETCH(st)
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
-            __builtin_amdgcn_sched_barrier(0);
-            ATBH_PARK(buf ^ 1)
-            __syncthreads();
-            buf ^= 1;
+        // step st: registers in slot st % NS (fetched NS - 1 iterations ago); unrolled by NS for static register indices
+        for (long long base_st = 1; base_st < steps; base_st += NS) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const long long st = base_st + i;
+                if (st < steps) {
+                    if (st + NS - 2 < steps) fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    park(R[(1 + i) % NS], buf ^ 1);
+                    __syncthreads();
+                    buf ^= 1;
+                }
+            }
         }
         compute(buf);
     }
-#undef ATBH_FETCH
-#undef ATBH_COL
-#undef ATBH_PARK
 
     float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
 #pragma unroll
