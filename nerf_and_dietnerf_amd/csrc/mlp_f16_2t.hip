@@ -153,6 +153,12 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
                         orgb[s][0] = fmaf(wr0[n & 3], y, orgb[s][0]);
                         orgb[s][1] = fmaf(wr1[n & 3], y, orgb[s][1]);
                         orgb[s][2] = fmaf(wr2[n & 3], y, orgb[s][2]);
+                        // The running sums are pinned to this k-step.  Left free, hipcc (ROCm 7.2) defers the second
+                        // set's whole 64-term chain to the end of the tile -- parking the activations in spare AGPRs
+                        // and keeping all 48 weight registers live -- and that build returned a wrong term for exactly
+                        // one (tile 2, register 7) of the second set's 64 (caught by test_fp16_single_pass_mode:
+                        // raw rgb vs the fp16 emulation); in place, both sets are handled alike.
+                        asm volatile("" : "+v"(orgb[s][0]), "+v"(orgb[s][1]), "+v"(orgb[s][2]));
                     } else if constexpr ((n & 1) == 0) ycarry[s] = y;
                     else store_pair(sc, std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry[s], y, std::false_type{});
                 }

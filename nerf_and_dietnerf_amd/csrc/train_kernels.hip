@@ -910,57 +910,95 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const GemmAtb g) {
     }
 }
 
-// fp16 activations (mixed_float16 policy): a thread owns two neighbouring columns of A (one 4-byte load per row) and the
-// last thread of the workgroup the column sums of G
-__global__ __launch_bounds__(256) void head_wgrad_f16_kernel(const GemmAtb g) {
+// fp16 activations (mixed_float16 policy).  A row of A is read as a whole by neighbouring threads (8 bytes = four columns
+// each): K / 4 column quads x RL row lanes per workgroup, four rows in flight per thread, the row lanes' partial sums
+// combined through LDS in a fixed order.  (The first version, one thread per column pair striding down the rows with
+// 4-byte loads, ran at 1.1 TB/s.)
+template <bool F16>      // F16: A holds fp16 elements (mixed_float16 policy); else fp32 (16-byte loads of four columns)
+__global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
+    __shared__ float red[256][17];                          // [thread][16 sums + 1 pad]
+    __shared__ float gsum[256][4];
     const int split = blockIdx.x, t = threadIdx.x;
     const long long ms = (long long)split * g.rows_per_split;
     const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
     float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
     const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
-    const bool ones = t == 255;                            // (Kp <= 320: the column pairs need at most 160 threads)
-    const int k0 = 2 * t;
-    const bool valid = ones || k0 < g.Kp;
-    const bool live = ones || k0 < g.K;                    // columns beyond K are padding: zeros, but written
-    float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (valid && live)
-        for (long long m = ms; m < me; m += 8) {
-            float av[8][2];
-            float4 gv[8];
+    const int KQ = g.Kp / 4;                               // column quads (Kp is a multiple of 4; <= 80)
+    const int RL = 256 / KQ;                               // row lanes
+    const int cq = t % KQ, rl = t / KQ;
+    const bool active = rl < RL;
+    const bool live = 4 * cq < g.K;                        // columns beyond K are padding
+    float a[4][4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                gv[q] = *reinterpret_cast<const float4*>(g.G + (m + q) * g.ldg);
-                if (ones) { av[q][0] = 1.0f; av[q][1] = 0.f; }
-                else {
-                    const h2v v = __builtin_bit_cast(h2v, *reinterpret_cast<const uint32_t*>(A + (m + q) * g.lda + k0));
-                    av[q][0] = (float)v[0]; av[q][1] = (float)v[1];
-                }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[c][q] = 0.f;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (long long m = ms + rl; m < me; m += 4LL * RL) {
+            uint2 av[4];
+            float4 af[4];
+            float4 gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long mm = m + (long long)u * RL;
+                const bool in = mm < me;
+                gv[u] = in ? *reinterpret_cast<const float4*>(g.G + mm * g.ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (F16) av[u] = in && live ? *reinterpret_cast<const uint2*>(A + mm * g.lda + 4 * cq) : make_uint2(0u, 0u);
+                else af[u] = in && live ? *reinterpret_cast<const float4*>(g.A + mm * g.lda + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    a[e][0] = fmaf(av[q][e], gv[q].x, a[e][0]); a[e][1] = fmaf(av[q][e], gv[q].y, a[e][1]);
-                    a[e][2] = fmaf(av[q][e], gv[q].z, a[e][2]); a[e][3] = fmaf(av[q][e], gv[q].w, a[e][3]);
+            for (int u = 0; u < 4; ++u) {
+                float x[4];
+                if constexpr (F16) {
+                    const h2v lo = __builtin_bit_cast(h2v, av[u].x), hi = __builtin_bit_cast(h2v, av[u].y);
+                    x[0] = (float)lo[0]; x[1] = (float)lo[1]; x[2] = (float)hi[0]; x[3] = (float)hi[1];
+                } else {
+                    x[0] = af[u].x; x[1] = af[u].y; x[2] = af[u].z; x[3] = af[u].w;
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a[c][0] = fmaf(x[c], gv[u].x, a[c][0]); a[c][1] = fmaf(x[c], gv[u].y, a[c][1]);
+                    a[c][2] = fmaf(x[c], gv[u].z, a[c][2]); a[c][3] = fmaf(x[c], gv[u].w, a[c][3]);
+                }
+                if (cq == 0) { gs[0] += gv[u].x; gs[1] += gv[u].y; gs[2] += gv[u].z; gs[3] += gv[u].w; }
+            }
         }
-    if (ones) {
-        float* o = part + (size_t)g.Kp * g.Nw;
-        o[0] = a[0][0]; o[1] = a[0][1]; o[2] = a[0][2]; o[3] = a[0][3];
-    } else if (valid) {
+    }
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if (k0 + e < g.Kp) {
-                float* o = part + (size_t)(k0 + e) * g.Nw;
-                o[0] = a[e][0]; o[1] = a[e][1]; o[2] = a[e][2]; o[3] = a[e][3];
-            }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[t][4 * c + q] = a[c][q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gsum[t][q] = gs[q];
+    __syncthreads();
+    // column `col` (Kp <= 320 of them), summed over the row lanes in a fixed order; thread 255 adds the column sums of G
+    for (int col = t; col < g.Kp; col += 256) {
+        const int q4 = col / 4, c = col % 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RL; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += red[r * KQ + q4][4 * c + q];
+        float* dst = part + (size_t)col * g.Nw;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    }
+    if (t == 255) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RL; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += gsum[r * KQ][q];
+        float* dst = part + (size_t)g.Kp * g.Nw;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
 }
 
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s) {
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    if (g.a_f16) {
-        hipLaunchKernelGGL(head_wgrad_f16_kernel, dim3((unsigned)splits), dim3(256), 0, s, g);
+    // rows read as a whole by neighbouring threads (needs at most 256 column quads; Kp <= 320 here); the column-strided
+    // head_wgrad_kernel stays for wider matrices
+    if (g.Kp % 4 == 0 && g.Kp <= 1024 && g.lda % 4 == 0) {
+        if (g.a_f16) hipLaunchKernelGGL(head_wgrad_rows_kernel<true>, dim3((unsigned)splits), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(head_wgrad_rows_kernel<false>, dim3((unsigned)splits), dim3(256), 0, s, g);
         return;
     }
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)splits), dim3(256), 0, s, g);

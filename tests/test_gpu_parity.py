@@ -675,6 +675,18 @@ def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):
         err_emu, err_f32 = float(np.abs(raw - emu).max()) / scale, float(np.abs(raw - ref).max()) / scale
         assert err_emu <= 2e-3, err_emu                      # same arithmetic up to fp32 summation order / RNE ties
         assert err_f32 <= 5e-2 and err_emu < err_f32         # and visibly fp16-class, not fp32-class
+        # every row of every workgroup tile shape (the kernel runs two 32-sample sets per wave: 256-row tiles with a
+        # ragged tail), both networks: one wrong term of the 128 -> 3 head shows up here at ~3e-3
+        for which, layers in ((0, coarse), (1, fine)):
+            for m in (4096 + 77, 1000, 333, 31):
+                raw_m = ctx.model_predict(which, xyz[:m] if m <= 4096 else np.concatenate([xyz, xyz[:m - 4096]]),
+                                          dirs[:m] if m <= 4096 else np.concatenate([dirs, dirs[:m - 4096]]))
+                x_m = xyz[:m] if m <= 4096 else np.concatenate([xyz, xyz[:m - 4096]])
+                d_m = dirs[:m] if m <= 4096 else np.concatenate([dirs, dirs[:m - 4096]])
+                emu_m = oracle.mlp_forward_fp16(layers, oracle.positional_encoding_for_xyz(x_m, 5),
+                                                oracle.positional_encoding_for_views(d_m, 4))
+                sc = max(1.0, float(np.abs(emu_m).max()))
+                assert float(np.abs(raw_m - emu_m).max()) / sc <= 2e-3, (which, m)
         o, d = golden_vec["rays_orig"], golden_vec["rays_dirs"]
         uc, uf = golden_vec["u_coarse"], golden_vec["u_fine"]
         out = ctx.render(o, d, uc.shape[1], uf.shape[1], uc, uf)
