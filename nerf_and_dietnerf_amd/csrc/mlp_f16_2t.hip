@@ -153,11 +153,9 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
                         orgb[s][0] = fmaf(wr0[n & 3], y, orgb[s][0]);
                         orgb[s][1] = fmaf(wr1[n & 3], y, orgb[s][1]);
                         orgb[s][2] = fmaf(wr2[n & 3], y, orgb[s][2]);
-                        // The running sums are pinned to this k-step.  Left free, hipcc (ROCm 7.2) defers the second
-                        // set's whole 64-term chain to the end of the tile -- parking the activations in spare AGPRs
-                        // and keeping all 48 weight registers live -- and that build returned a wrong term for exactly
-                        // one (tile 2, register 7) of the second set's 64 (caught by test_fp16_single_pass_mode:
-                        // raw rgb vs the fp16 emulation); in place, both sets are handled alike.
+                        // The running sums are pinned to this k-step: left free, hipcc defers the second set's whole
+                        // 64-term chain to the end of the tile (activations parked in spare AGPRs, all 48 weight registers
+                        // kept live) -- the long-lived values that the exec-mask bug described at the tile's end corrupted.
                         asm volatile("" : "+v"(orgb[s][0]), "+v"(orgb[s][1]), "+v"(orgb[s][2]));
                     } else if constexpr ((n & 1) == 0) ycarry[s] = y;
                     else store_pair(sc, std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry[s], y, std::false_type{});
@@ -316,20 +314,37 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_2t_kernel(const MlpArgs a) {
         }
         layer_body_2t<BODY_LAST, true>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
 
+        // Both sets' results are finished BEFORE any divergent code, and the divergent part is flat (one store region, one
+        // counter region).  hipcc (ROCm 7.2) was caught restoring a VGPR it had saved around a nested divergent region
+        // (`if (valid && h == 0) { store; if (not finite) atomicAdd }`) under the INNER region's exec mask: a value that was
+        // live across it (one activation of the second set's deferred rgb chain) came back clobbered in exactly the lanes
+        // that had taken the branch.  Nothing but the outputs is live across the stores now.
         const f32x4 bh = lds_read4(kLdsConst + kHConstBHead * 4);
+        f32x4 outv[2];
+        bool bad = false;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float o0 = orgb[s][0], o1 = orgb[s][1], o2 = orgb[s][2];
             o0 += __shfl_xor(o0, 32);
             o1 += __shfl_xor(o1, 32);
             o2 += __shfl_xor(o2, 32);
-            if (valid_[s] && h == 0) {
-                f32x4 out;
-                out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = sigma_raw[s];
-                *reinterpret_cast<f32x4*>(a.raw + m_[s] * 4) = out;
-                const float chk = out[0] + out[1] + out[2] + out[3];
-                if (a.nonfinite && !(fabsf(chk) <= 3.0e38f)) atomicAdd(a.nonfinite, 1ull);
+            outv[s][0] = o0 + bh[0]; outv[s][1] = o1 + bh[1]; outv[s][2] = o2 + bh[2]; outv[s][3] = sigma_raw[s];
+            const float chk = outv[s][0] + outv[s][1] + outv[s][2] + outv[s][3];
+            bad |= valid_[s] && h == 0 && !(fabsf(chk) <= 3.0e38f);
+        }
+        if (h == 0) {
+            if (valid_[0]) *reinterpret_cast<f32x4*>(a.raw + m_[0] * 4) = outv[0];
+            if (valid_[1]) *reinterpret_cast<f32x4*>(a.raw + m_[1] * 4) = outv[1];
+        }
+        // overflow / NaN watch: count rows (a lane may hold up to two), never hide
+        if (a.nonfinite && bad) {
+            unsigned long long n_bad = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float chk = outv[s][0] + outv[s][1] + outv[s][2] + outv[s][3];
+                n_bad += (valid_[s] && !(fabsf(chk) <= 3.0e38f)) ? 1ull : 0ull;
             }
+            atomicAdd(a.nonfinite, n_bad);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
