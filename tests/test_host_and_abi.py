@@ -113,3 +113,26 @@ def test_m0_invariant_of_the_fused_kernels(tmp_path):
         assert r.returncode == 0, r.stdout
         for p in isa:                       # the asm is really in there: the check is not vacuous
             assert "global_load_lds_dwordx4" in open(p).read()
+
+
+def test_exec_restore_lint(tmp_path):
+    """tools/check_exec_restore.py (run by the Makefile on the fused kernels' ISA): flags a vector instruction between the
+    join label of an `s_cbranch_execz` and the `s_or_b64 exec` that re-opens the outer mask -- the shape of the hipcc defect
+    DESIGN.md section 4.1c describes -- and passes the ISA of the current build."""
+    import glob
+    import subprocess
+    import sys as _sys
+    tool = os.path.join(ROOT, "tools", "check_exec_restore.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("\ts_and_saveexec_b64 s[0:1], s[40:41]\n\ts_cbranch_execz .LBB0_35\n\tv_mov_b32_e32 v42, v15\n"
+                   "\ts_cbranch_execz .LBB0_34\n.LBB0_34:\n\tv_mov_b32_e32 v15, v42\n.LBB0_35:\n"
+                   "\ts_or_b64 exec, exec, s[0:1]\n")
+    good = tmp_path / "good.s"
+    good.write_text("\ts_and_saveexec_b64 s[0:1], s[40:41]\n\ts_cbranch_execz .LBB0_35\n\tv_mov_b32_e32 v42, v15\n"
+                    ".LBB0_35:\n\ts_or_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v15, v42\n")
+    assert subprocess.run([_sys.executable, tool, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([_sys.executable, tool, str(good)], capture_output=True).returncode == 0
+    isa = sorted(glob.glob(os.path.join(ROOT, "build", "csrc", "mlp_*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if isa:
+        r = subprocess.run([_sys.executable, tool] + isa, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
