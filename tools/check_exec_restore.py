@@ -33,6 +33,8 @@ def check(path):
                 continue               # fall-through labels belong to the same join sequence
             if t.startswith("s_cbranch") or t.startswith("s_branch") or t.startswith("s_endpgm"):
                 break
+            if re.search(r"saveexec|\bexec\b", t.split(",")[0]) or re.match(r"s_\w+\s+exec", t):
+                break                  # EXEC is set afresh (an else-branch, a new region): what follows runs under a defined mask
             window.append((j, t))
     return hits
 
