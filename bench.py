@@ -321,6 +321,29 @@ def main():
             # BASELINE configs[3]: DietNeRF consistency-render shape (150x150, 55+55, batches of 2048 rays)
             cfg4 = dict(side_run(model, "f16x3", 20, 150, 150, 55, 55, c2w, FOV, batch=2048),
                         workload="150x150, 55 coarse + 55 fine, 2048-ray batches (src/DietNeRF.py:215-218), headline mode")
+            # ... and what DietNeRF does with that image: back-propagate dL/d(image) through NeRF.render, batch by batch
+            model.ctx.set_precision("f16x3")
+            model.compile(5e-4)
+            d_img = torch.rand((150 * 150, 3), device="cuda") * 1e-3
+            dirs4 = model.ctx.get_rays_directions(150, 150, FOV, torch.as_tensor(c2w, device="cuda")).reshape(-1, 4)
+            orig4 = torch.as_tensor(c2w[:, 3], device="cuda").expand(150 * 150, 4).contiguous()
+
+            def consistency_backward(seed):
+                for b in range(0, 150 * 150, 2048):
+                    model.ctx.train_render_gradients(orig4[b:b + 2048], dirs4[b:b + 2048], d_img[b:b + 2048], 55, 55,
+                                                     seed=seed, ray_base=b, accumulate=b > 0)
+            consistency_backward(0)
+            sync()
+            t4 = time.perf_counter()
+            for i in range(3):
+                consistency_backward(1 + i)
+            sync()
+            e4 = (time.perf_counter() - t4) / 3
+            model.ctx.train_end()
+            cfg4["render_gradients"] = {"ms_per_image": e4 * 1e3, "value": 150 * 150 / e4, "unit": "rays/s",
+                                        "note": "nerf_train_render_gradients: forward with stash + backward through the "
+                                                "merged 110-sample fine pass and the sampler, 11 batches of 2048 rays "
+                                                "(src/DietNeRF.py:204-222); fp32 policy"}
             # BASELINE configs[4]: 800x800, 64 coarse + 256 fine, fp16 MLP
             cfg5 = dict(side_run(model, "f16", 3, 800, 800, 64, 256, c2w, FOV),
                         workload="800x800, 64 coarse + 256 fine (fine pass 320 samples), single-pass fp16 MLP mode")

@@ -548,6 +548,54 @@ def test_backward_through_render(oracle, golden_ckpt, sampler_gradient, capsys):
     ctx.close()
 
 
+def test_dietnerf_consistency_step_shape(oracle, golden_ckpt, capsys):
+    """BASELINE configs[3], the caller shape of DietNeRF's consistency loss (src/DietNeRF.py:204-222) end to end: render a
+    150x150 image with 55 + 55 samples, let a stand-in for the embedding network (a fixed random linear map + cosine
+    similarity to a target embedding: the CLIP ViT itself is a remote fetch and out of scope) produce dL/d(image) on the
+    host, back-propagate it through NeRF.render batch by batch (2048-ray batches, same seed and ray_base as the image),
+    one Adam step on the accumulated gradients -- and the loss of the re-rendered image must go down."""
+    import nerf_and_dietnerf_amd as N
+    near, far, fov = float(golden_ckpt["near"]), float(golden_ckpt["far"]), float(golden_ckpt["fov"])
+    ctx = N.Context(near=near, far=far, precision="f16x3")
+    ctx.load_weights(0, golden_ckpt["blob_coarse"])
+    ctx.load_weights(1, golden_ckpt["blob_fine"])
+    ctx.train_begin(2e-4)
+    c2w = golden_ckpt["c2w_train"]
+    h = w = 150
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal((64, h * w * 3)).astype(np.float64) / np.sqrt(h * w * 3)     # the stand-in embedder
+    target = rng.standard_normal(64)
+    target /= np.linalg.norm(target)
+
+    def loss_and_grad(img):
+        x = img.reshape(-1).astype(np.float64) * 2 - 1                                    # embedder_preprocess range
+        e = emb @ x
+        n = np.linalg.norm(e)
+        cos = float(e @ target / n)
+        d_e = (target - cos * e / n) / n                                                  # d cos / d e
+        return 0.5 * (1 + cos), (0.5 * 2 * (emb.T @ d_e)).reshape(-1, 3).astype(np.float32)   # (1 + cos) / 2, :273
+
+    dirs = oracle.get_rays_directions(h, w, fov, c2w).reshape(-1, 4)
+    orig = np.broadcast_to(c2w[:, 3], dirs.shape).astype(np.float32)
+    losses = []
+    for step in range(4):
+        seed = 77 + step
+        img = ctx.render_image(c2w, fov, h, w, 2048, 55, 55, seed=seed)[0]
+        loss, d_img = loss_and_grad(img)
+        losses.append(loss)
+        for b in range(0, h * w, 2048):
+            rgb, _, _ = ctx.train_render_gradients(orig[b:b + 2048], dirs[b:b + 2048], d_img[b:b + 2048], 55, 55, seed=seed,
+                                                   ray_base=b, accumulate=b > 0)
+            if step == 0:          # the tape's forward is the image just rendered: same draws through (seed, ray_base)
+                assert np.abs(rgb - img.reshape(-1, 3)[b:b + 2048]).max() <= 1e-4
+        ctx.train_apply()
+    with capsys.disabled():
+        print("\n[DietNeRF-shaped consistency steps, 150x150 x (55 + 55)] stand-in loss per step: " +
+              " ".join(f"{x:.4f}" for x in losses))
+    assert losses[-1] < losses[0]
+    ctx.close()
+
+
 @pytest.mark.parametrize("alpha", [1.0, 0.05])
 def test_gradients_at_the_reference_sample_counts(oracle, golden_ckpt, alpha, capsys):
     """The float64 autograd oracle at the reference's own sample counts (64 coarse + 128 fine) on a 32-ray batch, sampler
