@@ -604,7 +604,10 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     // Four register stages of operand rows: one workgroup per CU and only 8 MFMAs per wave and 16-row step mean a step
     // lasts a few hundred cycles, far less than a global load's latency -- with the one-deep prefetch of gemm_atb_h this
     // kernel ran at the speed of that latency (2.5 TB/s).  Loads are issued three steps ahead of their use instead.
-    constexpr int NS = 4;
+#ifndef NERF_ATBF_STAGES
+#define NERF_ATBF_STAGES 4
+#endif
+    constexpr int NS = NERF_ATBF_STAGES;
     uint2 R[NS][4];
 #pragma unroll
     for (int q = 0; q < NS; ++q)

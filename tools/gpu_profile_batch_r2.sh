@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo/gpurun_out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/prof_r2_bench -o b --output-format csv -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --quick > $R/prof_r2_bench.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/prof_r2_train -o t --output-format csv -- python3 /root/repo/tools/train_bench.py 8 > $R/prof_r2_train.log 2>&1 || exit 1
-tail -1 $R/prof_r2_train.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/prof_r2_mixed -o m --output-format csv -- python3 /root/repo/tools/train_bench.py 8 4096 mixed > $R/prof_r2_mixed.log 2>&1 || exit 1
+grep train_step $R/prof_r2_train.log $R/prof_r2_mixed.log
 PMCSET="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"
 for mode in f16x3 f16; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMCSET -d $R/pmc2_${mode}a -o a --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --quick --precision $mode > $R/pmc2_${mode}a.log 2>&1 || exit 1
@@ -21,4 +22,7 @@ done
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc $PMCSET -d $R/pmc2_traina -o a --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > $R/pmc2_traina.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/pmc2_trainb -o b --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > $R/pmc2_trainb.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/pmc2_trainc -o c --output-format csv -- python3 /root/repo/tools/train_bench.py 2 > $R/pmc2_trainc.log 2>&1 || exit 1
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc $PMCSET -d $R/pmc2_mixeda -o a --output-format csv -- python3 /root/repo/tools/train_bench.py 2 4096 mixed > $R/pmc2_mixeda.log 2>&1 || exit 1
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/pmc2_mixedb -o b --output-format csv -- python3 /root/repo/tools/train_bench.py 2 4096 mixed > $R/pmc2_mixedb.log 2>&1 || exit 1
+timeout -k 10 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/pmc2_mixedc -o c --output-format csv -- python3 /root/repo/tools/train_bench.py 2 4096 mixed > $R/pmc2_mixedc.log 2>&1 || exit 1
 echo "pmc train ok"

@@ -19,6 +19,11 @@ KINDS = {  # tag -> [(kernel-name substring, label)]
               ("mlp_bwd_f16x3_kernel", "mlp_bwd_f16x3_kernel (fused data-gradient chain, coarse pass)"),
               ("gemm_atb_h_kernel<256>", "gemm_atb_h<256> (weight gradient, 3-pass split fp16)"),
               ("gemm_atb_h_kernel<128>", "gemm_atb_h<128> (weight gradient of layer 8)")],
+    "mixed": [("mlp_f16_stash_kernel", "mixed_float16 policy: mlp_f16_stash_kernel (single-pass forward, fp16 stash)"),
+              ("mlp_bwd_f16_dx_kernel", "mixed_float16 policy: mlp_bwd_f16_dx_kernel (single-pass backward chain, fine pass)"),
+              ("mlp_bwd_f16_kernel", "mixed_float16 policy: mlp_bwd_f16_kernel (single-pass backward chain, coarse pass)"),
+              ("gemm_atb_f16_kernel<256>", "mixed_float16 policy: gemm_atb_f16<256> (weight gradient on fp16 rows, one pass)"),
+              ("head_wgrad_rows_kernel", "mixed_float16 policy: head_wgrad_rows (the two heads' weight gradients)")],
 }
 
 
