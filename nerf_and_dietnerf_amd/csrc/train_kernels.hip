@@ -418,7 +418,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int b = t & (W - 1), rg = b & 3, cg = b >> 2;
     const int ld = isG ? g.ldg : g.lda;
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
-    const float* src = (isG ? g.G + nb : g.A + kb) + (ms + 4 * rg) * ld + 4 * cg;
+    // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
+    const float* src = (isG ? g.G : g.A) + (ms + 4 * rg) * ld + (on ? (isG ? nb : kb) + 4 * cg : 0);
     const float mul = isG ? gscale : 1.0f;
     const int wbase = (isG ? 2 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -433,24 +434,22 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;      // column sums of the raw G block (bias gradient)
 
     // Register stages of operand rows (NERF_ATBH_STAGES, default 3): with one 512-thread workgroup per CU a 16-row step
-    // lasts ~800 cycles, less than a global load's latency; loads are issued NS - 1 steps ahead of their use.
+    // lasts ~800 cycles, less than a global load's latency; loads are issued NS - 2 barriers ahead of their use.  The
+    // loop is branch-free (see gemm_atb_f16_kernel: loads inside conditional blocks made the compiler wait for vmcnt(0)
+    // before every LDS store); steps past the end read the last rows again and are zeroed when they are parked.
 #ifndef NERF_ATBH_STAGES
 #define NERF_ATBH_STAGES 3
 #endif
     constexpr int NS = NERF_ATBH_STAGES;
     float4 R[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) R[q][e] = zero4;
+    const long long steps = ms < me ? (me - ms) / 16 : 0;
     auto fetch = [&](float4 (&r)[4], long long st) {
-        if (on) {
-            const float* q_ = src + (size_t)st * 16 * ld;
-            r[0] = *reinterpret_cast<const float4*>(q_);
-            r[1] = *reinterpret_cast<const float4*>(q_ + ld);
-            r[2] = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);
-            r[3] = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);
-        }
+        const long long sc = st < steps ? st : steps - 1;
+        const float* q_ = src + (size_t)sc * 16 * ld;
+        r[0] = *reinterpret_cast<const float4*>(q_);
+        r[1] = *reinterpret_cast<const float4*>(q_ + ld);
+        r[2] = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);
+        r[3] = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);
     };
     auto col = [&](int jcol, float c0, float c1, float c2, float c3, int buf) {
         uint32_t h01, l01, h23, l23;
@@ -460,7 +459,11 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         *reinterpret_cast<uint2*>(w_) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(w_ + kPl) = make_uint2(l01, l23);
     };
-    auto park = [&](const float4 (&r)[4], int buf) {
+    auto park = [&](const float4 (&r_)[4], long long st, int buf) {
+        const bool live = on && st < steps;
+        float4 r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = live ? r_[e] : zero4;
         cs0 += (r[0].x + r[1].x) + (r[2].x + r[3].x); cs1 += (r[0].y + r[1].y) + (r[2].y + r[3].y);
         cs2 += (r[0].z + r[1].z) + (r[2].z + r[3].z); cs3 += (r[0].w + r[1].w) + (r[2].w + r[3].w);
         col(0, r[0].x, r[1].x, r[2].x, r[3].x, buf);
@@ -494,28 +497,25 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             }
     };
 
-    if (ms < me) {
-        const long long steps = (me - ms) / 16;
+    if (steps > 0) {
 #pragma unroll
-        for (int q = 0; q < NS - 1; ++q)
-            if (q < steps) fetch(R[q], q);
-        park(R[0], 0);
+        for (int q = 0; q < NS - 1; ++q) fetch(R[q], q);
+        park(R[0], 0, 0);
         __syncthreads();
         int buf = 0;
-        // step st: registers in slot st % NS (fetched NS - 1 iterations ago); unrolled by NS for static register indices
+        // step st: registers in slot st % NS; unrolled by NS for static register indices (the last round may run past the
+        // end: those steps park zeros)
         for (long long base_st = 1; base_st < steps; base_st += NS) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const long long st = base_st + i;
-                if (st < steps) {
-                    if (st + NS - 2 < steps) fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    compute(buf);
-                    __builtin_amdgcn_sched_barrier(0);
-                    park(R[(1 + i) % NS], buf ^ 1);
-                    __syncthreads();
-                    buf ^= 1;
-                }
+                fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(buf);
+                __builtin_amdgcn_sched_barrier(0);
+                park(R[(1 + i) % NS], st, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
             }
         }
         compute(buf);
@@ -568,7 +568,11 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     constexpr int kPl = W * kHColStride;
     constexpr int WNW = W / 64;
     constexpr int KTL = W / 64;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * kPl];    // planes: A, G
+#ifndef NERF_ATBF_PB
+#define NERF_ATBF_PB 2
+#endif
+    constexpr int PB = NERF_ATBF_PB;      // 16-row sub-steps per barrier
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][PB][2 * kPl];    // planes: A, G
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave / WNW, wn = wave % WNW;
     const int li = lane & 31, lh = lane >> 5;
@@ -589,7 +593,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int b = t & (W - 1), rg = b & 3, cg = b >> 2;
     const int ld = isG ? g.ldg : g.lda;
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
-    const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) + (isG ? nb : kb) + (ms + 4 * rg) * ld + 4 * cg;
+    // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) + (ms + 4 * rg) * ld + (on ? (isG ? nb : kb) + 4 * cg : 0);
     const int wbase = (isG ? 1 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
 
     f32x16 acc[KTL][2];
@@ -601,48 +606,60 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
 
-    // Four register stages of operand rows: one workgroup per CU and only 8 MFMAs per wave and 16-row step mean a step
-    // lasts a few hundred cycles, far less than a global load's latency -- with the one-deep prefetch of gemm_atb_h this
-    // kernel ran at the speed of that latency (2.5 TB/s).  Loads are issued three steps ahead of their use instead.
+    // Register stages of operand rows, each PB sub-steps, loaded NS - 2 barriers ahead of their use.  The loop is
+    // branch-free on purpose: with the loads inside "if (in range)" blocks the compiler's wait-count bookkeeping gave up
+    // at the joins and put s_waitcnt vmcnt(0) in front of every LDS store, i.e. it also waited for the loads it had just
+    // issued, and the kernel ran at one global-load latency per step (3.1 TB/s of HBM traffic; 4.6 TB/s without the branches).  Out-of-range sub-steps read the last
+    // valid rows again and are zeroed when they are parked.
 #ifndef NERF_ATBF_STAGES
 #define NERF_ATBF_STAGES 4
 #endif
-    constexpr int NS = NERF_ATBF_STAGES;
-    uint2 R[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) R[q][e] = make_uint2(0u, 0u);
+#ifndef NERF_ATBF_STAGES_WIDE
+#define NERF_ATBF_STAGES_WIDE 3
+#endif
+    constexpr int NS = W == 256 ? NERF_ATBF_STAGES_WIDE : NERF_ATBF_STAGES;   // the 256-wide tile has 128 accumulator registers
+    uint2 R[NS][PB][4];
     auto h2f = [](uint32_t w, int hi) -> float {
         const h2v v = __builtin_bit_cast(h2v, w);
         return (float)v[hi];
     };
-    auto fetch = [&](uint2 (&r)[4], long long st) {
-        if (on) {
-            const uint16_t* q_ = src + (size_t)st * 16 * ld;
-            r[0] = *reinterpret_cast<const uint2*>(q_);
-            r[1] = *reinterpret_cast<const uint2*>(q_ + ld);
-            r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)ld);
-            r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)ld);
-        }
+    long long steps = 0;
+    auto fetch1 = [&](uint2 (&r)[4], long long st) {
+        const long long sc = st < steps ? st : steps - 1;
+        const uint16_t* q_ = src + (size_t)sc * 16 * ld;
+        r[0] = *reinterpret_cast<const uint2*>(q_);
+        r[1] = *reinterpret_cast<const uint2*>(q_ + ld);
+        r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)ld);
+        r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)ld);
+    };
+    auto fetch = [&](uint2 (&r)[PB][4], long long pj) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) fetch1(r[p], pj * PB + p);
     };
     // column j of the 4 x 4 block = halfs (r0, r1, r2, r3)[j]: two byte permutes per column
-    auto park = [&](const uint2 (&r)[4], int buf) {
+    auto park1 = [&](const uint2 (&r_)[4], bool live, unsigned char* lbuf) {
+        uint2 r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = make_uint2(live ? r_[e].x : 0u, live ? r_[e].y : 0u);
         if (isG && first_ktile) {
             cs0 += (h2f(r[0].x, 0) + h2f(r[1].x, 0)) + (h2f(r[2].x, 0) + h2f(r[3].x, 0));
             cs1 += (h2f(r[0].x, 1) + h2f(r[1].x, 1)) + (h2f(r[2].x, 1) + h2f(r[3].x, 1));
             cs2 += (h2f(r[0].y, 0) + h2f(r[1].y, 0)) + (h2f(r[2].y, 0) + h2f(r[3].y, 0));
             cs3 += (h2f(r[0].y, 1) + h2f(r[1].y, 1)) + (h2f(r[2].y, 1) + h2f(r[3].y, 1));
         }
-        unsigned char* w_ = &lds[buf][wbase];
+        unsigned char* w_ = lbuf + wbase;
         *reinterpret_cast<uint2*>(w_ + 0 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x05040100u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x05040100u));
         *reinterpret_cast<uint2*>(w_ + 1 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].x, r[0].x, 0x07060302u), __builtin_amdgcn_perm(r[3].x, r[2].x, 0x07060302u));
         *reinterpret_cast<uint2*>(w_ + 2 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x05040100u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x05040100u));
         *reinterpret_cast<uint2*>(w_ + 3 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x07060302u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x07060302u));
     };
 
-    auto compute = [&](int buf) {
-        const unsigned char* base = lds[buf];
+    auto park = [&](const uint2 (&r)[PB][4], long long pj, int buf) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) park1(r[p], on && pj * PB + p < steps, lds[buf][p]);
+    };
+
+    auto compute1 = [&](const unsigned char* base) {
         h8v ah[KTL], gh[2];
 #pragma unroll
         for (int q = 0; q < KTL; ++q)
@@ -656,28 +673,32 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gh[c], acc[a][c], 0, 0, 0);
     };
 
-    if (ms < me) {
-        const long long steps = (me - ms) / 16;
+    auto compute = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NS - 1; ++q)
-            if (q < steps) fetch(R[q], q);
-        park(R[0], 0);
+        for (int p = 0; p < PB; ++p) compute1(lds[buf][p]);
+    };
+
+    steps = ms < me ? (me - ms) / 16 : 0;
+    if (steps > 0) {
+        const long long groups = (steps + PB - 1) / PB;
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) fetch(R[q], q);
+        park(R[0], 0, 0);
         __syncthreads();
         int buf = 0;
-        // step st: registers in slot st % NS (fetched NS - 1 iterations ago); unrolled by NS for static register indices
-        for (long long base_st = 1; base_st < steps; base_st += NS) {
+        // group st: registers in slot st % NS; unrolled by NS for static register indices.  The last round may run past
+        // the end: those groups park zeros.
+        for (long long base_st = 1; base_st < groups; base_st += NS) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const long long st = base_st + i;
-                if (st < steps) {
-                    if (st + NS - 2 < steps) fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    compute(buf);
-                    __builtin_amdgcn_sched_barrier(0);
-                    park(R[(1 + i) % NS], buf ^ 1);
-                    __syncthreads();
-                    buf ^= 1;
-                }
+                fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(buf);
+                __builtin_amdgcn_sched_barrier(0);
+                park(R[(1 + i) % NS], st, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
             }
         }
         compute(buf);
@@ -1016,11 +1037,14 @@ __device__ __forceinline__ int train_row_of_blob_row(int kb, int rowmap) {
     return kb;
 }
 
-// 8 lanes per gradient entry: lane q adds the partials of slabs q, q + 8, ... and the eight sums are combined in a fixed
-// butterfly -- the same order on every run (bit-reproducible gradients), 8x the loads in flight of a serial sum.
+// L lanes per gradient entry: lane q adds the partials of slabs q, q + L, ... and the L sums are combined in a fixed
+// butterfly -- the same order on every run (bit-reproducible gradients), L x the loads in flight of a serial sum.
+// L = 8 for the wide layers that do not take the vector path below, 64 for the heads (a few hundred entries, a thousand
+// slabs: with 8 lanes each thread walked 128 dependent-latency loads, 41 us per launch).
+template <int L>
 __global__ void reduce_grad_kernel(const ReduceArgs a) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = tid >> 3, q = tid & 7;
+    const int e = tid / L, q = tid % L;
     const int total = (a.K_real + 1) * a.N_real;
     const bool live = e < total;
     const int ee = live ? e : 0;
@@ -1031,19 +1055,63 @@ __global__ void reduce_grad_kernel(const ReduceArgs a) {
     const size_t stride = (size_t)(a.Kp + 1) * a.Nw;
     float s = 0.f;
     if (live)
-        for (int i = q; i < a.splits; i += 8) s += p[i * stride];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
+        for (int i = q; i < a.splits; i += L) s += p[i * stride];
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o);
     if (live && q == 0) {
         float* dst = is_bias ? a.grad_b + n : a.grad_w + (size_t)kb * a.N_real + n;
         *dst = a.accumulate ? *dst + s : s;
     }
 }
 
+// The wide layers (N_real, Nw and the source offset multiples of 4): a workgroup owns 64 float4 columns of the
+// [K + 1] x [N] gradient, its eight waves each add every eighth slab with 16-byte loads that cover whole 1 KiB rows of a
+// slab, and the eight sums meet in LDS in a fixed order.  (The 8-lane kernel read 32 bytes per row and instruction.)
+__global__ __launch_bounds__(512) void reduce_grad_vec_kernel(const ReduceArgs a) {
+    __shared__ float4 sm[8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n4 = a.N_real / 4, total4 = (a.K_real + 1) * n4;
+    const int c4 = blockIdx.x * 64 + lane;
+    const bool live = c4 < total4;
+    const int cc = live ? c4 : 0;
+    const int kb = cc / n4, n = 4 * (cc % n4);
+    const bool is_bias = kb == a.K_real;
+    const int kt = is_bias ? a.Kp : train_row_of_blob_row(kb, a.rowmap);
+    const float* p = a.partial + (size_t)kt * a.Nw + a.n_src_off + n;
+    const size_t stride = (size_t)(a.Kp + 1) * a.Nw;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+#pragma unroll 8
+        for (int i = w; i < a.splits; i += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
+        float r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* f = reinterpret_cast<const float*>(&sm[0][lane]) + c;
+            constexpr int W8 = 64 * 4;      // floats between the rows of sm
+            r[c] = ((f[0] + f[W8]) + (f[2 * W8] + f[3 * W8])) + ((f[4 * W8] + f[5 * W8]) + (f[6 * W8] + f[7 * W8]));
+        }
+        float* dst = is_bias ? a.grad_b + n : a.grad_w + (size_t)kb * a.N_real + n;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = a.accumulate ? dst[c] + r[c] : r[c];
+    }
+}
+
 void launch_reduce_grad(const ReduceArgs& a, hipStream_t s) {
-    const int total = (a.K_real + 1) * a.N_real * 8;
-    hipLaunchKernelGGL(reduce_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    const int entries = (a.K_real + 1) * a.N_real;
+    if (a.N_real % 4 == 0 && a.Nw % 4 == 0 && a.n_src_off % 4 == 0 && a.N_real >= 64) {
+        hipLaunchKernelGGL(reduce_grad_vec_kernel, dim3((entries / 4 + 63) / 64), dim3(512), 0, s, a);
+    } else if (entries <= 4096) {
+        hipLaunchKernelGGL(reduce_grad_kernel<64>, dim3((entries * 64 + 255) / 256), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(reduce_grad_kernel<8>, dim3((entries * 8 + 255) / 256), dim3(256), 0, s, a);
+    }
 }
 
 __global__ void relayout_kernel(const RelayoutArgs a) {
