@@ -15,6 +15,9 @@
 // epilogue as running sums, so the 64-float xc buffer of the one-tile kernel does not exist twice.
 #include "mlp_f16_frag.h"
 
+#ifndef NERF_2T_PE_LADDER
+#define NERF_2T_PE_LADDER 1     // positional encodings by angle doubling (nerf_device.h::sin_ladder_fp16_modes)
+#endif
 namespace nerf {
 
 namespace {
@@ -272,8 +275,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_2t_kernel(const MlpArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = c == 0 ? px : c == 1 ? py : pz;
+#if NERF_2T_PE_LADDER
+                sin_ladder_fp16_modes<kLx>(v * kPi, h, &pv[c * kLx]);
+#else
 #pragma unroll
                 for (int k = 0; k < kLx; ++k) pv[c * kLx + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+#endif
             }
             pv[15] = h ? 0.f : px; pv[16] = h ? 0.f : py; pv[17] = h ? 0.f : pz;
 #pragma unroll
@@ -289,8 +296,12 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_2t_kernel(const MlpArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = c == 0 ? dx : c == 1 ? dy : dz;
+#if NERF_2T_PE_LADDER
+                sin_ladder_fp16_modes<kLd>(v * kPi, h, &dv[c * kLd]);
+#else
 #pragma unroll
                 for (int k = 0; k < kLd; ++k) dv[c * kLd + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+#endif
             }
 #pragma unroll
             for (int i = 12; i < 16; ++i) dv[i] = 0.f;

@@ -368,8 +368,12 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = c == 0 ? px : c == 1 ? py : pz;
+            if constexpr (FAST) {
+                sin_ladder_fp16_modes<kLx>(v * kPi, h, &pv[c * kLx]);     // angle doubling: single-pass fp16 modes only
+            } else {
 #pragma unroll
-            for (int k = 0; k < kLx; ++k) pv[c * kLx + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+                for (int k = 0; k < kLx; ++k) pv[c * kLx + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+            }
         }
         pv[15] = h ? 0.f : px; pv[16] = h ? 0.f : py; pv[17] = h ? 0.f : pz;
 #pragma unroll
@@ -385,8 +389,12 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = c == 0 ? dx : c == 1 ? dy : dz;
+            if constexpr (FAST) {
+                sin_ladder_fp16_modes<kLd>(v * kPi, h, &dv[c * kLd]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < kLd; ++k) dv[c * kLd + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+                for (int k = 0; k < kLd; ++k) dv[c * kLd + k] = sin_shifted(v * (kPi * (float)(1 << k)), h);
+            }
         }
 #pragma unroll
         for (int i = 12; i < 16; ++i) dv[i] = 0.f;

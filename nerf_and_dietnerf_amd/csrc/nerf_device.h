@@ -26,6 +26,37 @@ __device__ __forceinline__ float sin_shifted(float th, int h) {
     return (q & 2) ? -v : v;
 }
 
+// out[k] = sin(2^k theta + h pi/2), k < L, for the SINGLE-PASS FP16 kernels only: one full evaluation of sin and cos at
+// k = 0 (same reduction and polynomials as sin_shifted) and the angle-doubling recurrence above it,
+// s' = 2 s c, c' = 1 - 2 s^2 -- 3 operations a level instead of ~22.  The error doubles per level (~2e-6 at k = 4),
+// two orders below the fp16 rounding the encodings get in those kernels; the fp32-class modes keep sin_shifted.
+template <int L>
+__device__ __forceinline__ void sin_ladder_fp16_modes(float th, int h, float* out) {
+    const float n = rintf(th * 0.6366197466850281f);
+    float r = fmaf(-n, 1.5707963705062866f, th);
+    r = fmaf(-n, -4.371138828673793e-08f, r);
+    r = fmaf(-n, -1.7151245100058819e-15f, r);
+    const int q = (int)n;
+    const float r2 = r * r;
+    float sp = fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? -sp : cp;
+    if (q & 2) { s = -s; c = -c; }
+    out[0] = h ? c : s;
+#pragma unroll
+    for (int k = 1; k < L; ++k) {
+        const float t = s + s;
+        const float s2 = t * c;
+        c = fmaf(-t, s, 1.0f);
+        s = s2;
+        out[k] = h ? c : s;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG: counter = (ray_lo, ray_hi, sample/4, stream), key = seed.
