@@ -186,6 +186,12 @@ def main():
                 raise
             a_img = None
             gather_check = f"c-level communicator unavailable ({type(e).__name__}: {e}); torch all-gather only"
+        # every rank takes the same branch below (the comparison contains a collective): all or none
+        ok_all = torch.tensor([1 if a_img is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+        if int(ok_all.item()) == 0 and a_img is not None:
+            a_img = None
+            gather_check = "c-level communicator unavailable on another rank; torch all-gather only"
         if a_img is not None:
             b_img = N.gather_slabs(model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=12345,
                                                       ray_begin=begin, ray_count=count, device_out=True,
