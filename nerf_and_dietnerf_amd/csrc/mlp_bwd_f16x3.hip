@@ -132,10 +132,12 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     float pc = 0.f;                          // packed-scale value waiting for its pair
     (void)q0; (void)q1; (void)q2; (void)pc;
     // true-scale store of registers r-3..r (r & 3 == 3) of a tile whose 32 rows start at column c0 of `base`
-    auto store4 = [&](float* base, int c0, int r, float v) {
+    // fragc: `base` is a fragment-major D buffer (train_kernels.h::frag_index: a feature offset c, c % 8 == 0, is the
+    // element offset 32 c from the lane's base); the dx buffers are row-major
+    auto store4 = [&](float* base, int c0, int r, float v, auto fragc) {
         f32x4 o;
         o[0] = q0; o[1] = q1; o[2] = q2; o[3] = v;
-        *reinterpret_cast<f32x4*>(base + c0 + 8 * (r >> 2)) = o;
+        *reinterpret_cast<f32x4*>(base + (decltype(fragc)::value ? 32 : 1) * (c0 + 8 * (r >> 2))) = o;
     };
     // register r of hidden tile ht: mask, write the true value, scale + split + pack into the next operand
     auto hidden_reg = [&](auto htc, auto rc, float acc_v, const frag4& mk, float inv_s, float rho_s, float* dst,
@@ -150,13 +152,13 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             // LossScaleOptimizer logic skips the step and halves the scale.
             if constexpr ((r & 1) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = __uint_as_float(pack_h2(q0, t));
-            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * ht + 8 * (r >> 2)) =
+            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))) =
                      make_uint2(__float_as_uint(q1), pack_h2(q0, t));
         } else {
             if constexpr ((r & 3) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = t;
             else if constexpr ((r & 3) == 2) q2 = t;
-            else store4(dst, 32 * ht, r, t);
+            else store4(dst, 32 * ht, r, t, std::true_type{});
         }
         const float pk = v * rho_s;
         L.mrun = fmaxf(L.mrun, fabsf(pk));
@@ -184,7 +186,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         if constexpr ((r & 3) == 0) q0 = t;
         else if constexpr ((r & 3) == 1) q1 = t;
         else if constexpr ((r & 3) == 2) q2 = t;
-        else store4(dx_cur, 32 * xt, r, t);
+        else store4(dx_cur, 32 * xt, r, t, std::false_type{});
     };
 
     static_for<0, NU>([&](auto uc) {
@@ -338,6 +340,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m = tile * 128 + wave * 32 + j;           // rows beyond M exist (padding) and carry zero Graw
+        const long long off128 = (m - j) * a.ld9 + (h * 32 + j) * 4; // this lane's slot in the fragment-major G9 rows
         // everything this tile reads from HBM, in one batch (a compiler-placed vmcnt wait drains the DMA ring once)
         const f32x4 graw = *reinterpret_cast<const f32x4*>(a.graw + m * 4);
         frag4 mq[9];
@@ -367,10 +370,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     mt = fmaxf(mt, fabsf(v));
                 }
                 if constexpr (FAST)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[8]) + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) =
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[8]) + off128 + 32 * (32 * t + 16 * s + 8 * g)) =
                         make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
                 else
-                    *reinterpret_cast<f32x4*>(a.d_ptr[8] + m * a.ld9 + 4 * h + 32 * t + 16 * s + 8 * g) = o;
+                    *reinterpret_cast<f32x4*>(a.d_ptr[8] + off128 + 32 * (32 * t + 16 * s + 8 * g)) = o;
             }
         }
         mt = max_with_other_half(mt);
@@ -406,7 +409,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             nl[8] = frag4{pack_h2(l0, 0.f), 0u, 0u, 0u};
         }
 
-        const long long off256 = m * a.ld + 4 * h;
+        const long long off256 = (m - j) * a.ld + (h * 32 + j) * 4;      // fragment-major D rows: block of 32 rows, lane slot
         float* d_prev = nullptr;
         // (FAST: the D rows are fp16; the pointers stay float* and are advanced in halfs)
         auto d_row = [&](int l) -> float* {
@@ -457,10 +460,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     tmax = fmaxf(tmax, fabsf(v));
                 }
                 if constexpr (FAST)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * 7 + 8 * (r >> 2)) =
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * (32 * 7 + 8 * (r >> 2))) =
                         make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
                 else
-                    *reinterpret_cast<f32x4*>(d_cur + 32 * 7 + 8 * (r >> 2)) = o;
+                    *reinterpret_cast<f32x4*>(d_cur + 32 * (32 * 7 + 8 * (r >> 2))) = o;
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);

@@ -33,7 +33,8 @@ __device__ unsigned long long g_stamps_h[16];
 // FAST = single-pass fp16 mode (NERF_PRECISION_F16: the reference's production mixed_float16 numerics): only the
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
 // STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
-// of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store.
+// of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store, in the
+// FRAGMENT-MAJOR layout of train_kernels.h::frag_index (a store instruction writes 1 KiB / 512 B of consecutive bytes).
 // FAST + STASH (the mixed_float16 policy's forward) writes the stash in fp16 -- the very dwords it packs as the next
 // layer's operand, four consecutive features per 8-byte store -- and st_prev / st_cur then point at fp16 rows.
 // It also records the LeakyReLU' masks the fused backward (mlp_bwd_f16x3.hip) multiplies by: one bit per activation
@@ -110,7 +111,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         else {
             f32x4 v;
             v[0] = sq0; v[1] = sq1; v[2] = y0; v[3] = y1;
-            *reinterpret_cast<f32x4*>(base + 32 * ut + 8 * (r >> 2)) = v;
+            *reinterpret_cast<f32x4*>(base + 32 * (32 * ut + 8 * (r >> 2))) = v;
         }
     };
     uint32_t sqh = 0u;               // fp16 stash: the first packed pair of the four features being collected
@@ -119,7 +120,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         if constexpr ((r & 3) == 0) sqh = ph;
-        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * ut + 8 * (r >> 2)) = make_uint2(sqh, ph);
+        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * (32 * ut + 8 * (r >> 2))) = make_uint2(sqh, ph);
     };
     auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel, auto pend_sel) {
         constexpr int ut = decltype(utc)::value;
@@ -412,8 +413,10 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             else {
                 // row offset in elements (st_ld[l] elements per row): fp32 elements, or fp16 ones under FAST (the pointer
                 // arithmetic below is in floats, so halve it there)
-                const long long row = a.diag_wrap ? (long long)(blockIdx.x * 8 + (j & 7)) : tile * 128 + wave * 32 + j;
-                const long long off = row * (long long)a.st_ld[l] + 4 * h;
+                // fragment-major rows (train_kernels.h::frag_index): the wave's 32 samples are one block, lane (h, j) owns
+                // the 4-element slot h * 32 + j of every 8-feature group; a feature offset c (c % 8 == 0) is 32 c elements
+                const long long row0 = a.diag_wrap ? (long long)(blockIdx.x & 63) * 128 + wave * 32 : tile * 128 + wave * 32;
+                const long long off = row0 * (long long)a.st_ld[l] + (h * 32 + j) * 4;
                 if constexpr (FAST) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.st_ptr[l]) + off);
                 else return a.st_ptr[l] + off;
             }

@@ -49,6 +49,7 @@ struct TrainState {
     bool fused_forward = false;     // forward pass on the fused split-fp16 kernel with activation stash (n_angles > 0)
     int32_t *sidx = nullptr, *cidx = nullptr;   // device gather tables of the fused kernel's stream / constants
     bool fused_backward = false;    // data gradients by the fused chain kernel (needs the fused forward's mask records)
+    bool frag = false;              // fused forward + backward: activation / gradient buffers are fragment-major (frag_index)
     int32_t* bidx[2] = {nullptr, nullptr};      // gather tables of the backward stream: [0] plain, [1] with encoding tiles
     long long step = 0;
     size_t nblob = 0;
@@ -257,7 +258,8 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
     TPass& p = t->pass[which];
     float *raw = (float*)p.raw.p, *z = (float*)p.z.p;
     launch_train_encode(o, dirs, z, 0, d.M, d.S, d.Mp, c->cfg.n_angles, 0, (float*)p.C4.p, (float*)p.C8.p, c->stream,
-                        t->mixed);
+                        t->mixed, t->frag);
+    if (t->frag && !n.fstream) return fail("internal: fused training forward without its weight stream");
     if (t->fused_forward && n.fstream) {
         // the render path's fused PE + MLP kernel (3-pass split fp16, fp32-class results) with every activation also
         // written to the buffers the backward GEMMs read: 4x the rate of the layer-wise forward
@@ -294,9 +296,10 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     const bool f16 = (t->wgrad_f16 && gmax && Ncols >= 128) || (t->mixed && Ncols >= 128);
     const bool wide = f16 && t->wgrad_wide && Ncols >= 256;
     g.a_f16 = t->mixed ? 1 : 0;
+    g.frag = t->frag ? 1 : 0;
     const int want_splits = Ncols == 4 ? 1024 : wide ? kTrainSplitsWide : kTrainSplits;
     long long rps = (Mp + want_splits - 1) / want_splits;
-    rps = (rps + 15) / 16 * 16;
+    rps = t->frag ? (rps + 31) / 32 * 32 : (rps + 15) / 16 * 16;     // fragment-major operands: whole 32-row blocks
     g.rows_per_split = (int)rps;
     g.gmax = gmax;
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
@@ -356,6 +359,8 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
     auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
     auto DS = [&](int l) -> const TLayer* { return t->dgrad_f16 && gm ? &n.L[l] : nullptr; };   // pre-split W of layer l
+    if (t->frag && !(n.bstream && n.fcst && p.masks.p && gm))
+        return fail("internal: fused training backward without its stream / mask records");
     if (t->fused_backward && n.bstream && n.fcst && p.masks.p && gm) {
         // ONE kernel for the whole data-gradient chain (mlp_bwd_f16x3.hip): the gradient stays on the lane from layer to
         // layer; every D_l is written once for the weight-gradient GEMMs below, with max|D_l| in the same gmax slots
@@ -379,8 +384,10 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5));
         wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6));
         wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7));
-        // (C4 + 256: the xyz encoding's columns -- 256 ELEMENTS in, i.e. half the byte offset under the fp16 policy)
-        const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + 256) : C4 + 256;
+        // (the xyz encoding's columns 256.. of C4: in the fragment-major buffer a column offset c is 32 c ELEMENTS --
+        // half the byte offset under the fp16 policy)
+        const size_t xyz_off = (size_t)32 * 256;
+        const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
         wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
@@ -799,15 +806,11 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     const char* bw = getenv("NERF_TRAIN_BACKWARD");
     t->fused_backward = t->fused_forward && t->dgrad_f16 && !(bw && strcmp(bw, "layers") == 0);
     t->ldh = 256; t->ldh9 = 128;
-    if (t->fused_forward && t->fused_backward) {
-        // measured (tools/train_bench.py, one device): pitch 256 -> 11.75 ms/step, 264 -> 12.75, 272 -> 12.88, 288 -> 11.95:
-        // rows that are not 128-B aligned cost more than any channel spreading gains, and line-aligned padding gains
-        // nothing -- the power-of-two pitch stays; the knob is kept for re-measuring on other devices
-        const char* lp = getenv("NERF_TRAIN_LDH");
-        t->ldh = lp ? atoi(lp) : 256;
-        if (t->ldh < 256 || t->ldh % 4) t->ldh = 256;
-        t->ldh9 = t->ldh == 256 ? 128 : 136;
-    }
+    // the fused forward writes fragment-major buffers that only the fused backward and the weight-gradient kernels read:
+    // both fused or neither (NERF_TRAIN_BACKWARD=layers, NERF_TRAIN_WGRAD / NERF_TRAIN_DGRAD=fp32 select the layer-wise
+    // GEMM forward as well)
+    if (!t->fused_backward) t->fused_forward = false;
+    t->frag = t->fused_forward && t->fused_backward;
     if (t->mixed && !(t->fused_forward && t->fused_backward)) {
         train_free(c);
         return fail("mixed_float16 training runs on the fused forward / backward kernels: unset NERF_TRAIN_FORWARD / "

@@ -14,6 +14,17 @@ constexpr int kDirPad = 32;
 constexpr int kTrainSplits = 128;   // row slabs of the weight-gradient reduction
 constexpr int kTrainSplitsWide = 256;   // ... with the 256 x 256 tile (one tile per slab for a 256 x 256 layer)
 
+// Fragment-major activation / gradient buffers (the fused training kernels): inside every block of 32 rows the elements
+// are ordered [feature / 8][(feature / 4) % 2][row % 32][feature % 4] -- the order in which the 64 lanes of a wave hold a
+// 32-sample x 8-feature accumulator slice (lane = 32 * half + sample, four consecutive features per lane).  One store
+// instruction of the fused forward / backward kernels then writes 512 (fp16) or 1024 (fp32) contiguous bytes instead of
+// 32 pieces of 16 / 32 bytes on 32 different rows, and the weight-gradient GEMMs read a thread's 4 x 4 block as 32 / 64
+// contiguous bytes.  Same footprint as row-major with pitch ld (ld % 8 == 0); a column offset c (c % 8 == 0) is the
+// pointer offset 32 * c.
+__host__ __device__ inline long long frag_index(long long row, int col, int ld) {
+    return (row >> 5) * 32 * ld + (((col >> 3) * 64 + ((col >> 2) & 1) * 32 + (int)(row & 31)) * 4 + (col & 3));
+}
+
 enum { EPI_FWD_LEAKY = 0, EPI_FWD_LINEAR = 1, EPI_BWD_MASK = 2, EPI_BWD_PLAIN = 3 };
 
 // Out[M x N] = epi( A[M x K] . Bt[N x K]^T )      (both operands K-contiguous)
@@ -48,6 +59,7 @@ struct GemmAtb {
     long long M; int rows_per_split;    // multiple of 16
     const unsigned* gmax;               // split-fp16 variant: bits of max|G| (written by G's producer); G is scaled to fp16 range
     int a_f16;                          // head_wgrad: A holds fp16 elements (lda in halfs); gemm_atb_f16: both operands do
+    int frag;                           // A and G (not the heads' 4-wide G) are fragment-major (frag_index below); rows_per_split % 32 == 0
 };
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
@@ -78,7 +90,8 @@ void launch_relayout(const RelayoutArgs& a, hipStream_t s);
 // rows [row0, row0 + M) of the sample grid (rays x S, or xyz/view rows in xyz_mode) -> local rows 0..M of C4/C8
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
                          long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s,
-                         bool half_out = false);   // half_out: C4 / C8 are fp16 rows of the same element pitch
+                         bool half_out = false,    // half_out: C4 / C8 are fp16 rows of the same element pitch
+                         bool frag = false);       // frag: C4 / C8 are fragment-major
 void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
                 hipStream_t s);
 void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, float inv_scale, int* all_finite, hipStream_t s);

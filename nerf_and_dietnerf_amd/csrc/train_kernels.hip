@@ -419,7 +419,10 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int ld = isG ? g.ldg : g.lda;
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
-    const float* src = (isG ? g.G : g.A) + (ms + 4 * rg) * ld + (on ? (isG ? nb : kb) + 4 * cg : 0);
+    const int col0 = on ? (isG ? nb : kb) + 4 * cg : 0;
+    // fragment-major operands (train_kernels.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive floats
+    const int rs = g.frag ? 4 : ld;                                   // floats between two of its rows
+    const float* src = (isG ? g.G : g.A) + (g.frag ? frag_index(ms + 4 * rg, col0, ld) : (ms + 4 * rg) * ld + col0);
     const float mul = isG ? gscale : 1.0f;
     const int wbase = (isG ? 2 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -445,11 +448,11 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const long long steps = ms < me ? (me - ms) / 16 : 0;
     auto fetch = [&](float4 (&r)[4], long long st) {
         const long long sc = st < steps ? st : steps - 1;
-        const float* q_ = src + (size_t)sc * 16 * ld;
+        const float* q_ = src + (g.frag ? (size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64 : (size_t)sc * 16 * ld);
         r[0] = *reinterpret_cast<const float4*>(q_);
-        r[1] = *reinterpret_cast<const float4*>(q_ + ld);
-        r[2] = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)ld);
-        r[3] = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)ld);
+        r[1] = *reinterpret_cast<const float4*>(q_ + rs);
+        r[2] = *reinterpret_cast<const float4*>(q_ + 2 * (size_t)rs);
+        r[3] = *reinterpret_cast<const float4*>(q_ + 3 * (size_t)rs);
     };
     auto col = [&](int jcol, float c0, float c1, float c2, float c3, int buf) {
         uint32_t h01, l01, h23, l23;
@@ -594,7 +597,11 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int ld = isG ? g.ldg : g.lda;
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
-    const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) + (ms + 4 * rg) * ld + (on ? (isG ? nb : kb) + 4 * cg : 0);
+    const int col = on ? (isG ? nb : kb) + 4 * cg : 0;
+    // fragment-major operands (train_kernels.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive elements
+    const int rs = g.frag ? 4 : ld;                                   // elements between two of its rows
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) +
+                          (g.frag ? frag_index(ms + 4 * rg, col, ld) : (ms + 4 * rg) * ld + col);
     const int wbase = (isG ? 1 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
 
     f32x16 acc[KTL][2];
@@ -626,11 +633,11 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     long long steps = 0;
     auto fetch1 = [&](uint2 (&r)[4], long long st) {
         const long long sc = st < steps ? st : steps - 1;
-        const uint16_t* q_ = src + (size_t)sc * 16 * ld;
+        const uint16_t* q_ = src + (g.frag ? (size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64 : (size_t)sc * 16 * ld);
         r[0] = *reinterpret_cast<const uint2*>(q_);
-        r[1] = *reinterpret_cast<const uint2*>(q_ + ld);
-        r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)ld);
-        r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)ld);
+        r[1] = *reinterpret_cast<const uint2*>(q_ + rs);
+        r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)rs);
+        r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)rs);
     };
     auto fetch = [&](uint2 (&r)[PB][4], long long pj) {
 #pragma unroll
@@ -949,8 +956,11 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
     const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
     const int KQ = g.Kp / 4;                               // column quads (Kp is a multiple of 4; <= 80)
     const int RL = 256 / KQ;                               // row lanes
-    const int cq = t % KQ, rl = t / KQ;
-    const bool active = rl < RL;
+    // row-major A: neighbouring threads read one row; fragment-major A: neighbouring threads read neighbouring rows of
+    // one column quad (consecutive 32 / 64-byte pieces)
+    const int cq = g.frag ? t / RL : t % KQ, rl = g.frag ? t % RL : t / KQ;
+    const bool active = t < KQ * RL;
+    auto thread_of = [&](int r, int q4) { return g.frag ? q4 * RL + r : r * KQ + q4; };
     const bool live = 4 * cq < g.K;                        // columns beyond K are padding
     float a[4][4];
 #pragma unroll
@@ -959,17 +969,21 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         for (int q = 0; q < 4; ++q) a[c][q] = 0.f;
     float gs[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
-        for (long long m = ms + rl; m < me; m += 4LL * RL) {
+        // four consecutive rows per thread and round (the slab starts at a multiple of 4): in a fragment-major A they are
+        // 16 consecutive elements
+        const int rs = g.frag ? 4 : g.lda;
+        for (long long m = ms + 4 * rl; m < me; m += 4LL * RL) {
             uint2 av[4];
             float4 af[4];
             float4 gv[4];
+            const long long a0 = g.frag ? frag_index(m, 4 * cq, g.lda) : m * g.lda + 4 * cq;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long long mm = m + (long long)u * RL;
+                const long long mm = m + u;
                 const bool in = mm < me;
                 gv[u] = in ? *reinterpret_cast<const float4*>(g.G + mm * g.ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (F16) av[u] = in && live ? *reinterpret_cast<const uint2*>(A + mm * g.lda + 4 * cq) : make_uint2(0u, 0u);
-                else af[u] = in && live ? *reinterpret_cast<const float4*>(g.A + mm * g.lda + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (F16) av[u] = in && live ? *reinterpret_cast<const uint2*>(A + a0 + (long long)u * rs) : make_uint2(0u, 0u);
+                else af[u] = in && live ? *reinterpret_cast<const float4*>(g.A + a0 + (long long)u * rs) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1002,7 +1016,7 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < RL; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += red[r * KQ + q4][4 * c + q];
+            for (int q = 0; q < 4; ++q) o[q] += red[thread_of(r, q4)][4 * c + q];
         float* dst = part + (size_t)col * g.Nw;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
@@ -1010,7 +1024,7 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < RL; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += gsum[r * KQ][q];
+            for (int q = 0; q < 4; ++q) o[q] += gsum[thread_of(r, 0)][q];
         float* dst = part + (size_t)g.Kp * g.Nw;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
@@ -1165,12 +1179,16 @@ void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float l
 template <typename T>      // T = float, or _Float16 for the mixed_float16 policy's half-width activation buffers
 __global__ void train_encode_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                     const float* __restrict__ z, long long row0, long long M, int S, long long Mp,
-                                    int n_angles, int xyz_mode, T* __restrict__ C4, T* __restrict__ C8) {
+                                    int n_angles, int xyz_mode, T* __restrict__ C4, T* __restrict__ C8, int frag) {
     // local row m of this chunk = global sample row row0 + m; xyz_mode: o = xyz (M,3), d = view_dirs (M,3) or null
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mp) return;
-    T* ex = C4 + m * kLdC4 + 256;
-    T* ed = C8 + m * kLdC8 + 256;
+    // element i of this row's xyz / direction encoding (columns 256 + i of the concat buffers)
+    struct Cols {
+        T* base; long long m; int ld; int frag;
+        __device__ T& operator[](int i) const { return base[frag ? frag_index(m, 256 + i, ld) : m * ld + 256 + i]; }
+    };
+    const Cols ex{C4, m, kLdC4, frag}, ed{C8, m, kLdC8, frag};
     if (m >= M) {
         for (int i = 0; i < kXyzPad; ++i) ex[i] = (T)0.f;
         for (int i = 0; i < kDirPad; ++i) ed[i] = (T)0.f;
@@ -1213,14 +1231,16 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
 }
 
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
-                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s, bool half_out) {
+                         long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s, bool half_out,
+                         bool frag) {
     if (Mp <= 0) return;
     const dim3 grid((unsigned)((Mp + 255) / 256)), block(256);
     if (half_out)
         hipLaunchKernelGGL(train_encode_kernel<_Float16>, grid, block, 0, s, o, d, z, row0, M, S, Mp, n_angles, xyz_mode,
-                           reinterpret_cast<_Float16*>(C4), reinterpret_cast<_Float16*>(C8));
+                           reinterpret_cast<_Float16*>(C4), reinterpret_cast<_Float16*>(C8), frag ? 1 : 0);
     else
-        hipLaunchKernelGGL(train_encode_kernel<float>, grid, block, 0, s, o, d, z, row0, M, S, Mp, n_angles, xyz_mode, C4, C8);
+        hipLaunchKernelGGL(train_encode_kernel<float>, grid, block, 0, s, o, d, z, row0, M, S, Mp, n_angles, xyz_mode, C4, C8,
+                           frag ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
