@@ -956,11 +956,8 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
     const uint16_t* A = reinterpret_cast<const uint16_t*>(g.A);
     const int KQ = g.Kp / 4;                               // column quads (Kp is a multiple of 4; <= 80)
     const int RL = 256 / KQ;                               // row lanes
-    // row-major A: neighbouring threads read one row; fragment-major A: neighbouring threads read neighbouring rows of
-    // one column quad (consecutive 32 / 64-byte pieces)
-    const int cq = g.frag ? t / RL : t % KQ, rl = g.frag ? t % RL : t / KQ;
-    const bool active = t < KQ * RL;
-    auto thread_of = [&](int r, int q4) { return g.frag ? q4 * RL + r : r * KQ + q4; };
+    const int cq = t % KQ, rl = t / KQ;
+    const bool active = rl < RL;
     const bool live = 4 * cq < g.K;                        // columns beyond K are padding
     float a[4][4];
 #pragma unroll
@@ -969,21 +966,17 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         for (int q = 0; q < 4; ++q) a[c][q] = 0.f;
     float gs[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
-        // four consecutive rows per thread and round (the slab starts at a multiple of 4): in a fragment-major A they are
-        // 16 consecutive elements
-        const int rs = g.frag ? 4 : g.lda;
-        for (long long m = ms + 4 * rl; m < me; m += 4LL * RL) {
+        for (long long m = ms + rl; m < me; m += 4LL * RL) {
             uint2 av[4];
             float4 af[4];
             float4 gv[4];
-            const long long a0 = g.frag ? frag_index(m, 4 * cq, g.lda) : m * g.lda + 4 * cq;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long long mm = m + u;
+                const long long mm = m + (long long)u * RL;
                 const bool in = mm < me;
                 gv[u] = in ? *reinterpret_cast<const float4*>(g.G + mm * g.ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (F16) av[u] = in && live ? *reinterpret_cast<const uint2*>(A + a0 + (long long)u * rs) : make_uint2(0u, 0u);
-                else af[u] = in && live ? *reinterpret_cast<const float4*>(g.A + a0 + (long long)u * rs) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (F16) av[u] = in && live ? *reinterpret_cast<const uint2*>(A + mm * g.lda + 4 * cq) : make_uint2(0u, 0u);
+                else af[u] = in && live ? *reinterpret_cast<const float4*>(g.A + mm * g.lda + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1016,7 +1009,7 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < RL; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += red[thread_of(r, q4)][4 * c + q];
+            for (int q = 0; q < 4; ++q) o[q] += red[r * KQ + q4][4 * c + q];
         float* dst = part + (size_t)col * g.Nw;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
@@ -1024,13 +1017,93 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < RL; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += gsum[thread_of(r, 0)][q];
+            for (int q = 0; q < 4; ++q) o[q] += gsum[r * KQ][q];
         float* dst = part + (size_t)g.Kp * g.Nw;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
 }
 
+// Fragment-major A (the fused trainer, train_kernels.h::frag_index): for one column quad the 32 rows of a block are 256
+// (fp16) or 512 (fp32) consecutive bytes.  Eight neighbouring lanes share a column quad and take four rows each -- a
+// whole block per round, one contiguous run per quad -- over all the slab's blocks; their sums meet in a fixed shuffle
+// butterfly (no LDS), lane 0 of the eight writes the 4 x 4 results.  A workgroup covers 32 quads per pass over the slab.
+template <bool F16>
+__global__ __launch_bounds__(256) void head_wgrad_frag_kernel(const GemmAtb g) {
+    const int split = blockIdx.x, t = threadIdx.x, rl = t & 7;
+    const long long ms = (long long)split * g.rows_per_split;           // multiple of 32
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(g.A);
+    const int KQ = g.Kp / 4;
+    for (int cq = t >> 3; cq < KQ; cq += 32) {
+        const bool live = 4 * cq < g.K;                    // columns beyond K are padding
+        float a[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[c][q] = 0.f;
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (long long m = ms + 4 * rl; m < me; m += 32) {
+            const long long a0 = frag_index(m, 4 * cq, g.lda);
+            float x[4][4];
+            if constexpr (F16) {
+                uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
+                if (live) { v0 = *reinterpret_cast<const uint4*>(A16 + a0); v1 = *reinterpret_cast<const uint4*>(A16 + a0 + 8); }
+                const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const h2v lo = __builtin_bit_cast(h2v, w[2 * u]), hi = __builtin_bit_cast(h2v, w[2 * u + 1]);
+                    x[u][0] = (float)lo[0]; x[u][1] = (float)lo[1]; x[u][2] = (float)hi[0]; x[u][3] = (float)hi[1];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = live ? *reinterpret_cast<const float4*>(g.A + a0 + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 gv = *reinterpret_cast<const float4*>(g.G + (m + u) * g.ldg);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a[c][0] = fmaf(x[u][c], gv.x, a[c][0]); a[c][1] = fmaf(x[u][c], gv.y, a[c][1]);
+                    a[c][2] = fmaf(x[u][c], gv.z, a[c][2]); a[c][3] = fmaf(x[u][c], gv.w, a[c][3]);
+                }
+                gs[0] += gv.x; gs[1] += gv.y; gs[2] += gv.z; gs[3] += gv.w;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[c][q] += __shfl_xor(a[c][q], o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gs[q] += __shfl_xor(gs[q], o);
+        }
+        if (rl == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float* dst = part + (size_t)(4 * cq + c) * g.Nw;
+                dst[0] = a[c][0]; dst[1] = a[c][1]; dst[2] = a[c][2]; dst[3] = a[c][3];
+            }
+            if (cq == 0) {      // column sums of G (bias gradient)
+                float* dst = part + (size_t)g.Kp * g.Nw;
+                dst[0] = gs[0]; dst[1] = gs[1]; dst[2] = gs[2]; dst[3] = gs[3];
+            }
+        }
+    }
+}
+
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s) {
+    if (g.frag) {
+        const int fsplits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+        if (g.a_f16) hipLaunchKernelGGL(head_wgrad_frag_kernel<true>, dim3((unsigned)fsplits), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(head_wgrad_frag_kernel<false>, dim3((unsigned)fsplits), dim3(256), 0, s, g);
+        return;
+    }
     const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
     // rows read as a whole by neighbouring threads (needs at most 256 column quads; Kp <= 320 here); the column-strided
     // head_wgrad_kernel stays for wider matrices
