@@ -132,8 +132,8 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     float pc = 0.f;                          // packed-scale value waiting for its pair
     (void)q0; (void)q1; (void)q2; (void)pc;
     // true-scale store of registers r-3..r (r & 3 == 3) of a tile whose 32 rows start at column c0 of `base`
-    // fragc: `base` is a fragment-major D buffer (train_kernels.h::frag_index: a feature offset c, c % 8 == 0, is the
-    // element offset 32 c from the lane's base); the dx buffers are row-major
+    // fragc: `base` is a fragment-major buffer (train_kernels.h::frag_index: a feature offset c, c % 8 == 0, is the
+    // element offset 32 c from the lane's base) -- D and dx both are
     auto store4 = [&](float* base, int c0, int r, float v, auto fragc) {
         f32x4 o;
         o[0] = q0; o[1] = q1; o[2] = q2; o[3] = v;
@@ -186,7 +186,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         if constexpr ((r & 3) == 0) q0 = t;
         else if constexpr ((r & 3) == 1) q1 = t;
         else if constexpr ((r & 3) == 2) q2 = t;
-        else store4(dx_cur, 32 * xt, r, t, std::false_type{});
+        else store4(dx_cur, 32 * xt, r, t, std::true_type{});
     };
 
     static_for<0, NU>([&](auto uc) {
@@ -417,8 +417,9 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             else return a.d_ptr[l] + off256;
         };
         float* d_cur = d_row(7);
-        float* dxa = DX ? a.dx_ptr[0] + m * kBwdXyzLd + 4 * h : nullptr;
-        float* dxb = DX ? a.dx_ptr[1] + m * kBwdXyzLd + 4 * h : nullptr;
+        const long long offx = (m - j) * kBwdXyzLd + (h * 32 + j) * 4;      // the dx rows are fragment-major as well
+        float* dxa = DX ? a.dx_ptr[0] + offx : nullptr;
+        float* dxb = DX ? a.dx_ptr[1] + offx : nullptr;
         frag4 mk_prev = mq[1], mk_cur = mq[1];
         bwd_body<BW_HEAD, 0, false, FAST>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
                                     nh, nl);

@@ -391,7 +391,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
-            launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream);
+            launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream, true);
         }
         HIP_OK(hipGetLastError());
         return 0;

@@ -100,7 +100,8 @@ void launch_composite_bwd(const float* raw, const float* z, const float* T, long
 void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,
                      long long M, float alpha, float* G9, unsigned* gmax, hipStream_t s);
 void launch_pe_bwd(const float* dA0, const float* dA0b /* added to dA0, or null */, const float* o, const float* d,
-                   const float* z, long long N, int S, float* d_z, hipStream_t s);
+                   const float* z, long long N, int S, float* d_z, hipStream_t s,
+                   bool frag = false);     // frag: dA0 / dA0b are fragment-major (the fused backward chain's dx buffers)
 void launch_unmerge_grad(const float* z_new, const float* z_c, const float* d_zm, long long N, int S, int Sf, float* d_zf,
                          hipStream_t s);
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,

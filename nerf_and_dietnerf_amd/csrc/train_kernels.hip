@@ -1320,20 +1320,20 @@ void launch_train_encode(const float* o, const float* d, const float* z, long lo
 // MSE (Keras MeanSquaredError = mean over all N*3 values, src/NeRF.py:50,151) and its gradient.
 // One workgroup, fixed reduction order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
-                                                  long long n3, float loss_scale, float* __restrict__ d_rgb,
-                                                  float* __restrict__ out) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
+                                                   long long n3, float loss_scale, float* __restrict__ d_rgb,
+                                                   float* __restrict__ out) {
+    __shared__ float red[1024];
     const float scale = loss_scale * 2.0f / (float)n3;      // loss_scale: LossScaleOptimizer.get_scaled_loss (1 = none)
     float s = 0.f;
-    for (long long i = threadIdx.x; i < n3; i += 256) {
+    for (long long i = threadIdx.x; i < n3; i += 1024) {
         const float e = rgb[i] - tgt[i];
         s = fmaf(e, e, s);
         d_rgb[i] = e * scale;
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb,
 
 void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
                 hipStream_t s) {
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, s, rgb, target, N * 3, loss_scale, d_rgb, mse_out);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, rgb, target, N * 3, loss_scale, d_rgb, mse_out);
 }
 
 // LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
@@ -1475,7 +1475,7 @@ void launch_head_bwd(const float* Graw, const float* W9, const float* H9, long l
 // ------------------------------------------------------------------------------------------------
 __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __restrict__ dA0b /* second part to add, or null */,
                               const float* __restrict__ o, const float* __restrict__ d,
-                              const float* __restrict__ z, long long M, int S, float* __restrict__ d_z) {
+                              const float* __restrict__ z, long long M, int S, float* __restrict__ d_z, int frag) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const long long r = m / S;
@@ -1486,13 +1486,14 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
                         __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
     const float dv[3] = {dd.x, dd.y, dd.z};
     // the encoding gradient may come in two parts (fused backward: through layer 4 and through layer 0)
-    const float* ga = dA0 + m * kXyzPad;
-    const float* gb = dA0b ? dA0b + m * kXyzPad : nullptr;
+    // frag: the (Mp, 64) rows are fragment-major (train_kernels.h::frag_index; written by the fused backward chain):
+    // neighbouring threads read neighbouring 16-byte slots
     float g[36];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {                  // 33 floats, read as 9 float4 (rows are 64 floats: no overrun)
-        float4 v = reinterpret_cast<const float4*>(ga)[q];
-        if (gb) { const float4 w = reinterpret_cast<const float4*>(gb)[q]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        const long long e = frag ? frag_index(m, 4 * q, kXyzPad) : m * kXyzPad + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(dA0 + e);
+        if (dA0b) { const float4 w = *reinterpret_cast<const float4*>(dA0b + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
         g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
     }
     float acc = 0.f;
@@ -1538,10 +1539,11 @@ void launch_unmerge_grad(const float* z_new, const float* z_c, const float* d_zm
 }
 
 void launch_pe_bwd(const float* dA0, const float* dA0b, const float* o, const float* d, const float* z, long long N, int S,
-                   float* d_z, hipStream_t s) {
+                   float* d_z, hipStream_t s, bool frag) {
     const long long M = N * S;
     if (M <= 0) return;
-    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, dA0, dA0b, o, d, z, M, S, d_z);
+    hipLaunchKernelGGL(pe_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, dA0, dA0b, o, d, z, M, S, d_z,
+                       frag ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
