@@ -264,50 +264,74 @@ void launch_sample_pdf(const float* weights, const float* z, long long N, int S,
 }
 
 // ------------------------------------------------------------------------------------------------
-// composite: one ray per thread, sequential along the ray (exclusive cumprod and the rgb / depth
-// sums in the canonical left-to-right order).
+// composite (ray_marching, src/UtilsNeuralRadianceField.py:88-115): ONE RAY PER WAVEFRONT.  The 64 lanes take 64
+// consecutive samples (one coalesced 1 KiB read of the raw rows), alpha / sigmoid -- the expensive part -- are evaluated
+// in parallel, the exclusive transmittance travels through the lanes in the canonical left-to-right order (below),
+// carried from one 64-sample chunk to the next, and the rgb / depth sums are per-lane partial sums closed by a
+// butterfly (same terms as a left-to-right loop, another association: a few ulps).  Same result on every run and
+// for every batching of the rays.  The first version walked one ray per LANE: 64 wavefronts for a 4096-ray batch and
+// a 3 KiB stride between the lanes of a load.
 // ------------------------------------------------------------------------------------------------
-__global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, long long N, int S,
-                                 float* __restrict__ rgb, float* __restrict__ weights,
-                                 float* __restrict__ cumprod, float* __restrict__ alpha_out,
-                                 float* __restrict__ rgb_samples, float* __restrict__ depth) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                        long long N, int S, float* __restrict__ rgb,
+                                                        float* __restrict__ weights, float* __restrict__ cumprod,
+                                                        float* __restrict__ alpha_out, float* __restrict__ rgb_samples,
+                                                        float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;                                        // uniform per wavefront
     const float4* rw = reinterpret_cast<const float4*>(raw) + r * S;
     const float* zr = z + r * S;
-    float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f;
-    float zc = zr[0];
-    for (int s = 0; s < S; ++s) {
-        const float4 o = rw[s];
-        const float zn = s + 1 < S ? zr[s + 1] : 0.f;
-        const float delta = s + 1 < S ? __fsub_rn(zn, zc) : 1e9f;
+    float carry = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool in = s < S;
+        const float4 o = in ? rw[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float zc = in ? zr[s] : 0.f;
+        const float delta = s + 1 < S ? zr[s + 1] - zc : 1e9f;
         const float sigma = fmaxf(o.w, 0.f);
-        const float a = __fsub_rn(1.0f, expf(-__fmul_rn(sigma, delta)));
-        const float r0 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-o.x)));
-        const float r1 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-o.y)));
-        const float r2 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-o.z)));
-        const float w = __fmul_rn(a, T);
-        c0 = __fadd_rn(c0, __fmul_rn(w, r0));
-        c1 = __fadd_rn(c1, __fmul_rn(w, r1));
-        c2 = __fadd_rn(c2, __fmul_rn(w, r2));
-        dep = __fadd_rn(dep, __fmul_rn(w, zc));
-        const long long m = r * S + s;
-        if (weights) weights[m] = w;
-        if (cumprod) cumprod[m] = T;
-        if (alpha_out) alpha_out[m] = a;
-        if (rgb_samples) { rgb_samples[m * 3 + 0] = r0; rgb_samples[m * 3 + 1] = r1; rgb_samples[m * 3 + 2] = r2; }
-        T = __fmul_rn(T, __fsub_rn(1.0f, a));
-        zc = zn;
+        const float a = in ? 1.0f - expf(-(sigma * delta)) : 0.f;
+        const float r0 = 1.0f / (1.0f + expf(-o.x));
+        const float r1 = 1.0f / (1.0f + expf(-o.y));
+        const float r2 = 1.0f / (1.0f + expf(-o.z));
+        // Exclusive transmittance in the canonical order T_l = fl(T_(l-1) * (1 - alpha_(l-1))): lane l reads its left
+        // neighbour through a one-lane wavefront shift (DPP wave_shr:1; lane 0 keeps the carry) and multiplies; after k
+        // rounds lanes 0..k are final and recomputing them changes nothing, so 63 rounds of one shift + one multiply
+        // finish the chunk.  (A tree-shaped prefix product is six steps, but neighbouring T then differ from the
+        // ratio 1 - alpha by a few ulps -- the inverse-CDF sampler amplifies exactly that, by up to 1e5.)
+        const float om = 1.0f - a;
+        const float oms = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(1.0f), __float_as_int(om), 0x138, 0xf, 0xf, false));
+        float T = lane == 0 ? carry : 1.0f;
+        const int rounds = S - s0 < 64 ? S - s0 - 1 : 63;
+        for (int k = 0; k < rounds; ++k) {
+            const float Ts = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(T), 0x138, 0xf, 0xf, false));
+            T = Ts * (lane == 0 ? 1.0f : oms);
+        }
+        const float w = a * T;
+        c0 += w * r0; c1 += w * r1; c2 += w * r2; dep += w * zc;
+        if (in) {
+            const long long m = r * S + s;
+            if (weights) weights[m] = w;
+            if (cumprod) cumprod[m] = T;
+            if (alpha_out) alpha_out[m] = a;
+            if (rgb_samples) { rgb_samples[m * 3 + 0] = r0; rgb_samples[m * 3 + 1] = r1; rgb_samples[m * 3 + 2] = r2; }
+        }
+        carry = __shfl(T * om, 63);
     }
-    if (rgb) { rgb[r * 3 + 0] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2; }
-    if (depth) depth[r] = dep;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); dep += __shfl_xor(dep, o);
+    }
+    if (lane == 0) {
+        if (rgb) { rgb[r * 3 + 0] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2; }
+        if (depth) depth[r] = dep;
+    }
 }
 
 void launch_composite(const float* raw, const float* z, long long N, int S, float* rgb, float* weights,
                       float* cumprod, float* alpha, float* rgb_samples, float* depth, hipStream_t stream) {
     if (N <= 0) return;
-    const int bs = 64;
-    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((N + bs - 1) / bs)), dim3(bs), 0, stream, raw, z, N, S,
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, raw, z, N, S,
                        rgb, weights, cumprod, alpha, rgb_samples, depth);
 }
 

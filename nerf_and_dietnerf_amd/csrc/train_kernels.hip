@@ -1370,55 +1370,76 @@ void launch_unscale_check(float* ga, float* gb, size_t n, float inv_scale, int* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// compositing backward (ray_marching, src/UtilsNeuralRadianceField.py:88-115), one ray per thread,
-// reverse sweep.  With T_i the exclusive transmittance and g_w[i] = dL/dw_i:
+// compositing backward (ray_marching, src/UtilsNeuralRadianceField.py:88-115), one ray per wavefront like the forward
+// (aux_kernels.hip::composite_kernel).  With T_i the exclusive transmittance and g_w[i] = dL/dw_i:
 //     dL/dalpha_i = T_i * (g_w[i] - R_i),   R_{i-1} = g_w[i]*alpha_i + (1 - alpha_i)*R_i,   R_{S-1} = 0
 // (no division by 1 - alpha, which is exactly 0 wherever sigma*delta overflows, e.g. the 1e9 last interval).
+// alpha, the sigmoids and the output rows are evaluated in parallel over 64-sample chunks taken from the far end of the
+// ray; the reverse recurrence travels through the lanes in its canonical order (below).
 // ------------------------------------------------------------------------------------------------
-__global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
-                                     const float* __restrict__ Tin, long long N, int S,
-                                     const float* __restrict__ d_rgb, const float* __restrict__ d_w_ext,
-                                     float* __restrict__ Graw, float* __restrict__ d_z) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                            const float* __restrict__ Tin, long long N, int S,
+                                                            const float* __restrict__ d_rgb,
+                                                            const float* __restrict__ d_w_ext, float* __restrict__ Graw,
+                                                            float* __restrict__ d_z) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;                                        // uniform per wavefront
     const float4* rw = reinterpret_cast<const float4*>(raw) + r * S;
     float4* gr = reinterpret_cast<float4*>(Graw) + r * S;
     const float* zr = z + r * S;
     const float g0 = d_rgb[r * 3 + 0], g1 = d_rgb[r * 3 + 1], g2 = d_rgb[r * 3 + 2];
-    float R = 0.f, prev_dd = 0.f;
-    for (int s = S - 1; s >= 0; --s) {
-        const float4 o = rw[s];
-        const bool last = s + 1 == S;
+    float Rc = 0.f;          // R entering the current chunk from the far side
+    float dd_far = 0.f;      // dL/ddelta of the first sample of the chunk processed before (the next one along the ray)
+    for (int s0 = (S - 1) / 64 * 64; s0 >= 0; s0 -= 64) {
+        const int s = s0 + lane;
+        const bool in = s < S, last = s + 1 >= S;
+        const float4 o = in ? rw[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float delta = last ? 1e9f : zr[s + 1] - zr[s];
         const float sigma = fmaxf(o.w, 0.f);
-        const float e = expf(-sigma * delta);        // 1 - alpha
+        const float e = in ? expf(-sigma * delta) : 1.0f;       // 1 - alpha
         const float a = 1.0f - e;
-        const float T = Tin[r * S + s];
+        const float T = in ? Tin[r * S + s] : 0.f;
         const float c0 = 1.0f / (1.0f + expf(-o.x)), c1 = 1.0f / (1.0f + expf(-o.y)), c2 = 1.0f / (1.0f + expf(-o.z));
         const float w = a * T;
         float gw = g0 * c0 + g1 * c1 + g2 * c2;
-        if (d_w_ext) gw += d_w_ext[r * S + s];
-        const float da = T * (gw - R);
-        R = gw * a + e * R;
-        float4 out;
-        out.x = w * g0 * c0 * (1.0f - c0);
-        out.y = w * g1 * c1 * (1.0f - c1);
-        out.z = w * g2 * c2 * (1.0f - c2);
-        out.w = o.w > 0.f ? da * delta * e : 0.f;
-        gr[s] = out;
-        if (d_z) {
-            const float dd = last ? 0.f : da * sigma * e;     // dL/ddelta_s
-            if (!last) d_z[r * S + s + 1] = dd - prev_dd;
-            prev_dd = dd;
+        if (d_w_ext && in) gw += d_w_ext[r * S + s];
+        // R in the canonical order R_l = fl(fl(g_w a)_(l+1) + fl(e_(l+1) R_(l+1))): lane l reads its right neighbour through
+        // a one-lane wavefront shift (DPP wave_shl:1; lane 63 keeps the value carried in from the chunk beyond) --
+        // after k rounds lanes 63-k..63 are final, recomputing them changes nothing.  (A tree-shaped scan over the
+        // affine maps is six steps, but neighbouring R then carry unrelated roundings and d_z, a difference of
+        // neighbours that the sampler backward multiplies by up to 1e5, loses a digit and a half.)
+        const float bs = in ? gw * a : 0.f;
+        const float esh = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(1.0f), __float_as_int(e), 0x130, 0xf, 0xf, false));
+        const float bsh = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(0.0f), __float_as_int(bs), 0x130, 0xf, 0xf, false));
+        float R = lane == 63 ? Rc : 0.f;
+        for (int k = 0; k < 63; ++k) {
+            const float Rn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(R), __float_as_int(R), 0x130, 0xf, 0xf, false));
+            R = lane == 63 ? Rn : bsh + esh * Rn;
         }
+        const float da = T * (gw - R);
+        const float dd = last || !in ? 0.f : da * sigma * e;               // dL/ddelta_s
+        const float dd_right = __shfl_down(dd, 1);       // (unconditional: a shuffle under "lane != 63" reads 0 from lane 63)
+        const float dd_next = lane == 63 ? dd_far : dd_right;
+        if (in) {
+            float4 out;
+            out.x = w * g0 * c0 * (1.0f - c0);
+            out.y = w * g1 * c1 * (1.0f - c1);
+            out.z = w * g2 * c2 * (1.0f - c2);
+            out.w = o.w > 0.f ? da * delta * e : 0.f;
+            gr[s] = out;
+            if (d_z && !last) d_z[r * S + s + 1] = dd - dd_next;
+        }
+        Rc = __shfl(bs + e * R, 0);
+        dd_far = __shfl(dd, 0);
     }
-    if (d_z) d_z[r * S] = -prev_dd;
+    if (d_z && lane == 0) d_z[r * S] = -dd_far;
 }
 
 void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
                           const float* d_w_ext, float* Graw, float* d_z, hipStream_t s) {
     if (N <= 0) return;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s, raw, z, T, N, S, d_rgb,
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, raw, z, T, N, S, d_rgb,
                        d_w_ext, Graw, d_z);
 }
 

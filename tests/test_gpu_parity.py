@@ -396,9 +396,10 @@ def test_render_video_loop(nerf, golden_vec):
         full = nerf.render_image(poses[f], fov, 16, 16, seed=40 + f)
         np.testing.assert_array_equal(rgb[f], full[0])
         ref_depth = np.zeros((16, 16), np.float32)
-        for s in range(full[1].shape[-1]):                             # canonical left-to-right sum
+        for s in range(full[1].shape[-1]):
             ref_depth = ref_depth + full[1][..., s] * full[5][..., s]
-        np.testing.assert_array_equal(dep[f], ref_depth)
+        # the compositing kernel adds per-lane partial sums (one ray per wavefront): same terms, another association
+        np.testing.assert_allclose(dep[f], ref_depth, rtol=0, atol=1e-6)
     rgb2, dep2 = video.render_video(nerf, poses, fov, 16, 16, seed=40, loops=2)
     assert rgb2.shape[0] == 6 and dep2.min() >= 0.0 and dep2.max() <= 1.0
 
