@@ -66,11 +66,8 @@ struct TrainState {
     // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients
     // and the dynamic loss scale of Keras' LossScaleOptimizer
     bool mixed = false;
-    float loss_scale = 1.f;
-    int good_steps = 0, growth_steps = 2000;
-    long long skipped = 0;
-    bool last_finite = true;        // verdict of the latest gradients (unscale + finiteness test)
-    DevBuf flag;                    // device int: all gradients finite
+    bool last_finite = true;        // host copy of the latest verdict, read back only by the gradients / apply split API
+    DevBuf opt;                     // OptState (train_kernels.h): loss scale, verdicts, Adam iteration count -- on the device
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
@@ -500,7 +497,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, (float*)pf.z.p, nullptr,
                           c->stream);
         if (int q = forward_pass(c, t, 1, df, o, d)) return q;
-        launch_mse((const float*)pf.rgb.p, tg, N, t->loss_scale, d_rgb, scal + 1, c->stream);
+        launch_mse((const float*)pf.rgb.p, tg, N, (const OptState*)t->opt.p, d_rgb, scal + 1, c->stream);
         HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
         float* d_zf = through_sampler ? (float*)t->d_zf.p : nullptr;
         launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sf, d_rgb, nullptr,
@@ -510,41 +507,35 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
             launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, d_zf,
                                   (float*)t->d_wext.p, c->stream);
     }
-    launch_mse((const float*)pc.rgb.p, tg, N, t->loss_scale, d_rgb, scal + 0, c->stream);
+    launch_mse((const float*)pc.rgb.p, tg, N, (const OptState*)t->opt.p, d_rgb, scal + 0, c->stream);
     HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
     launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, d_rgb,
                          through_sampler ? (const float*)t->d_wext.p : nullptr, Graw, nullptr, c->stream);
     if (int q = backward_pass(c, t, 0, dc, o, d, nullptr)) return q;
     if (t->mixed) {
-        // LossScaleOptimizer: unscale, test for Inf/NaN; the verdict decides in finish_loss_scale() whether the step is
-        // applied.  (The per-sample scaling of the backward chain makes the products themselves scale-invariant; the
-        // loss scale still guards the compositing / sampler backward and gives the reference's skip-step behaviour.)
-        if (int q = ensure(c, t->flag, sizeof(int))) return q;
-        const int one = 1;
-        HIP_OK(hipMemcpyAsync(t->flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        launch_unscale_check(t->net[0].grad, fine ? t->net[1].grad : nullptr, t->nblob, 1.0f / t->loss_scale,
-                             (int*)t->flag.p, c->stream);
+        // LossScaleOptimizer: unscale, test for Inf/NaN; the verdict is taken on the device (opt_verdict_kernel) and gates
+        // this step's Adam update.  (The per-sample scaling of the backward chain makes the products themselves
+        // scale-invariant; the loss scale still guards the compositing / sampler backward and gives the reference's
+        // skip-step behaviour.)
+        launch_unscale_check(t->net[0].grad, fine ? t->net[1].grad : nullptr, t->nblob, (OptState*)t->opt.p, c->stream);
     }
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-// mixed_float16 policy: read the finiteness verdict of the gradients just computed and move the dynamic loss scale
-// (Keras 2.7 LossScaleOptimizer: halve on a non-finite step, double after `growth_steps` finite ones).
-int finish_loss_scale(nerf_ctx* c) {
+// The verdict of the gradients just computed, on the device: loss-scale bookkeeping (mixed_float16 policy: Keras 2.7
+// LossScaleOptimizer -- halve on a non-finite step, double after `growth` finite ones) and the flag that lets this step's
+// Adam launches through.  No host round trip: nerf_train_step keeps enqueuing.
+void take_verdict(nerf_ctx* c) { launch_opt_verdict((OptState*)c->train->opt.p, c->stream); }
+
+// ... and its host copy, for the gradients / apply split API whose caller decides between the two calls
+int read_verdict(nerf_ctx* c) {
     TrainState* t = c->train;
-    if (!t->mixed) { t->last_finite = true; return 0; }
-    int ok = 1;
-    HIP_OK(hipMemcpyAsync(&ok, t->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (!t->mixed) { t->last_finite = true; return 0; }     // the float32 policy never drops a step
+    OptState h;
+    HIP_OK(hipMemcpyAsync(&h, t->opt.p, sizeof(OptState), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    t->last_finite = ok != 0;
-    if (t->last_finite) {
-        if (++t->good_steps >= t->growth_steps) { t->loss_scale *= 2.f; t->good_steps = 0; }
-    } else {
-        t->loss_scale = t->loss_scale > 1.f ? t->loss_scale * 0.5f : 1.f;
-        t->good_steps = 0;
-        t->skipped += 1;
-    }
+    t->last_finite = h.apply_ok != 0;
     return 0;
 }
 
@@ -654,18 +645,19 @@ int read_metrics(nerf_ctx* c, bool fine, float* metrics) {
 }
 
 int apply_impl(nerf_ctx* c) {
+    // Adam (gated on the device by the latest verdict: a dropped step leaves weights, moments and the iteration count
+    // alone), then the training matrices are re-laid out from the blob either way
     TrainState* t = c->train;
-    t->step += 1;
-    const double b1 = t->cfg.beta_1, b2 = t->cfg.beta_2;
-    const double lr_t = (double)t->cfg.learning_rate * sqrt(1.0 - pow(b2, (double)t->step)) / (1.0 - pow(b1, (double)t->step));
+    OptState* st = (OptState*)t->opt.p;
     for (int w = 0; w < 2; ++w) {
         TNet& n = t->net[w];
         if (!n.present) continue;
-        launch_adam(n.blob, n.m, n.v, n.grad, t->nblob, (float)lr_t, t->cfg.beta_1, t->cfg.beta_2, t->cfg.epsilon,
-                    c->stream);
+        launch_adam(n.blob, n.m, n.v, n.grad, t->nblob, t->cfg.learning_rate, t->cfg.beta_1, t->cfg.beta_2, t->cfg.epsilon,
+                    st, c->stream);
         if (int r = relayout_net(c, n)) return r;
         n.render_dirty = true;
     }
+    launch_opt_tick(st, t->cfg.beta_1, t->cfg.beta_2, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -700,7 +692,7 @@ void train_free(nerf_ctx* c) {
         for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
-                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->flag};
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->opt};
     for (DevBuf* b : bs) free_buf(*b);
     delete t;
     c->train = nullptr;
@@ -782,13 +774,20 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     }
     t->cfg = *cfg;
     t->training = true;
-    t->step = 0;
     t->mixed = cfg->mixed_float16 != 0;
     if (t->mixed && c->cfg.n_angles == 0) { train_free(c); return fail("mixed_float16 training is not built for the xyz-only network"); }
-    t->loss_scale = t->mixed ? (cfg->initial_loss_scale > 0.f ? cfg->initial_loss_scale : 32768.f) : 1.f;
-    t->growth_steps = cfg->dynamic_growth_steps > 0 ? cfg->dynamic_growth_steps : 2000;
-    t->good_steps = 0;
-    t->skipped = 0;
+    {
+        OptState h{};
+        h.scale = t->mixed ? (cfg->initial_loss_scale > 0.f ? cfg->initial_loss_scale : 32768.f) : 1.f;
+        h.inv_scale = 1.0f / h.scale;
+        h.adam_corr = (float)(sqrt(1.0 - (double)cfg->beta_2) / (1.0 - (double)cfg->beta_1));      // t = 1
+        h.finite = 1; h.apply_ok = 1; h.good = 0;
+        h.growth = cfg->dynamic_growth_steps > 0 ? cfg->dynamic_growth_steps : 2000;
+        h.dynamic = t->mixed ? 1 : 0;
+        h.iterations = 0; h.skipped = 0;
+        if (int r = ensure(c, t->opt, sizeof(OptState))) { train_free(c); return r; }
+        HIP_OK(hipMemcpy(t->opt.p, &h, sizeof(OptState), hipMemcpyHostToDevice));
+    }
     t->last_finite = true;
     // forward on the fused kernel unless the network has no fused kernel (xyz-only) or NERF_TRAIN_FORWARD=gemm asks
     // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
@@ -849,9 +848,12 @@ int nerf_train_end(nerf_ctx* c) {
 
 int nerf_train_loss_scale(nerf_ctx* c, float* loss_scale, int64_t* steps_applied, int64_t* steps_skipped) {
     if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
-    if (loss_scale) *loss_scale = c->train->loss_scale;
-    if (steps_applied) *steps_applied = c->train->step;
-    if (steps_skipped) *steps_skipped = c->train->skipped;
+    OptState h;
+    HIP_OK(hipMemcpyAsync(&h, c->train->opt.p, sizeof(OptState), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (loss_scale) *loss_scale = h.scale;
+    if (steps_applied) *steps_applied = h.iterations;
+    if (steps_skipped) *steps_skipped = h.skipped;
     return 0;
 }
 
@@ -869,7 +871,8 @@ int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_
     if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
     TrainState* t = c->train;
     const bool fine = Sf > 0 && t->net[1].present;
-    if (int r = finish_loss_scale(c)) return r;          // mixed_float16: nerf_train_apply skips a non-finite step
+    take_verdict(c);
+    if (int r = read_verdict(c)) return r;               // mixed_float16: nerf_train_apply skips a non-finite step
     const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
     if (grad_fine) {
@@ -931,9 +934,8 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
     // (a non-finite shard gradient makes the all-reduced blob non-finite on every rank: ranks agree by themselves only
     //  when the test runs after the all-reduce -- single-rank here; the data-parallel path is nerf_train_gradients +
     //  the caller's all-reduce + nerf_train_apply, where the caller shares the verdict)
-    if (int r = finish_loss_scale(c)) return r;
-    if (c->train->last_finite)
-        if (int r = apply_impl(c)) return r;
+    take_verdict(c);
+    if (int r = apply_impl(c)) return r;                 // gated on the device by the verdict
     return read_metrics(c, fine, metrics);
 }
 

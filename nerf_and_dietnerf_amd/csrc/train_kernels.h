@@ -92,9 +92,24 @@ void launch_train_encode(const float* o, const float* d, const float* z, long lo
                          long long Mp, int n_angles, int xyz_mode, float* C4, float* C8, hipStream_t s,
                          bool half_out = false,    // half_out: C4 / C8 are fp16 rows of the same element pitch
                          bool frag = false);       // frag: C4 / C8 are fragment-major
-void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
-                hipStream_t s);
-void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, float inv_scale, int* all_finite, hipStream_t s);
+// Optimizer / loss-scale state kept ON THE DEVICE: the verdict of a step's gradients (mixed_float16 policy: Keras 2.7
+// LossScaleOptimizer, src/NeRF.py:159-163) gates that step's Adam update and moves the loss scale of the next step
+// without the host reading anything back -- the host keeps enqueuing steps ahead of the GPU.
+struct OptState {
+    float scale, inv_scale;      // current loss scale (1 under the float32 policy)
+    float adam_corr;             // sqrt(1 - beta_2^t) / (1 - beta_1^t) for the NEXT update, t = iterations + 1
+    int finite;                  // being collected by unscale_check for the gradients in flight (1 = all finite so far)
+    int apply_ok;                // verdict of the latest gradients: Adam applies them only if set
+    int good, growth;            // finite steps since the scale last changed / finite steps that double it
+    int dynamic;                 // 1 under the mixed_float16 policy
+    long long iterations;        // Adam updates applied
+    long long skipped;           // steps dropped because their gradients were not finite
+};
+void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float* d_rgb, float* mse_out,
+                hipStream_t s);         // d_rgb carries st->scale (LossScaleOptimizer.get_scaled_loss)
+void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, OptState* st, hipStream_t s);
+void launch_opt_verdict(OptState* st, hipStream_t s);                          // after the gradients: scale bookkeeping, apply_ok
+void launch_opt_tick(OptState* st, float beta1, float beta2, hipStream_t s);   // after Adam: iterations, adam_corr
 void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,
                           const float* d_w_ext, float* Graw, float* d_z, hipStream_t s);
 void launch_head_bwd(const float* Graw, const float* W9 /*[128][Np9] row-major, Np9 = 32*/, const float* H9,
@@ -107,7 +122,7 @@ void launch_unmerge_grad(const float* z_new, const float* z_c, const float* d_zm
 void launch_sample_pdf_bwd(const float* weights, const float* z, long long N, int S, int Sf, const float* u,
                            uint64_t seed, long long ray_base, const float* d_zf, float* d_w, hipStream_t s);
 size_t sample_pdf_bwd_lds_bytes(int S, int Sf);
-void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2,
-                 float eps, hipStream_t s);
+void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr, float beta1, float beta2, float eps,
+                 const OptState* st, hipStream_t s);      // no-op unless st->apply_ok; lr_t = lr * st->adam_corr
 
 }  // namespace nerf

@@ -1226,10 +1226,12 @@ void launch_relayout(const RelayoutArgs& a, hipStream_t s) {
 }
 
 __global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ g, size_t n, float lr_t, float b1, float b2, float eps) {
+                            const float* __restrict__ g, size_t n, float lr, float b1, float b2, float eps,
+                            const OptState* __restrict__ st) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || !st->apply_ok) return;          // LossScaleOptimizer.apply_gradients drops a non-finite step
     // Keras-2.7 Adam, dense non-amsgrad update (lr_t carries the bias correction; epsilon is not rescaled)
+    const float lr_t = lr * st->adam_corr;
     const float gi = g[i];
     const float mi = m[i] + (gi - m[i]) * (1.f - b1);
     const float vi = v[i] + (gi * gi - v[i]) * (1.f - b2);
@@ -1238,10 +1240,42 @@ __global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float*
     w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
 
-void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float beta1, float beta2,
-                 float eps, hipStream_t s) {
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, m, v, g, n, lr_t, beta1,
-                       beta2, eps);
+void launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr, float beta1, float beta2, float eps,
+                 const OptState* st, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, m, v, g, n, lr, beta1, beta2,
+                       eps, st);
+}
+
+// One thread: the verdict of the gradients just computed.  mixed_float16 policy = Keras 2.7 LossScaleOptimizer with
+// dynamic scaling: a non-finite step is dropped and halves the scale, `growth` finite steps in a row double it.
+__global__ void opt_verdict_kernel(OptState* st) {
+    const int ok = st->finite;
+    st->apply_ok = ok;
+    if (st->dynamic) {
+        if (ok) {
+            if (++st->good >= st->growth) { st->scale *= 2.f; st->good = 0; }
+        } else {
+            st->scale = st->scale > 1.f ? st->scale * 0.5f : 1.f;
+            st->good = 0;
+            st->skipped += 1;
+        }
+        st->inv_scale = 1.0f / st->scale;
+    }
+    st->finite = 1;
+}
+
+void launch_opt_verdict(OptState* st, hipStream_t s) { hipLaunchKernelGGL(opt_verdict_kernel, dim3(1), dim3(1), 0, s, st); }
+
+// One thread, after the Adam launches of a step: count the update and prepare the next bias correction (in double)
+__global__ void opt_tick_kernel(OptState* st, float b1, float b2) {
+    if (!st->apply_ok) return;
+    st->iterations += 1;
+    const double t = (double)(st->iterations + 1);
+    st->adam_corr = (float)(sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
+
+void launch_opt_tick(OptState* st, float beta1, float beta2, hipStream_t s) {
+    hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, s, st, beta1, beta2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,10 +1355,10 @@ void launch_train_encode(const float* o, const float* d, const float* z, long lo
 // One workgroup, fixed reduction order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
-                                                   long long n3, float loss_scale, float* __restrict__ d_rgb,
-                                                   float* __restrict__ out) {
+                                                   long long n3, const OptState* __restrict__ st,
+                                                   float* __restrict__ d_rgb, float* __restrict__ out) {
     __shared__ float red[1024];
-    const float scale = loss_scale * 2.0f / (float)n3;      // loss_scale: LossScaleOptimizer.get_scaled_loss (1 = none)
+    const float scale = st->scale * 2.0f / (float)n3;      // st->scale: LossScaleOptimizer.get_scaled_loss (1 = none)
     float s = 0.f;
     for (long long i = threadIdx.x; i < n3; i += 1024) {
         const float e = rgb[i] - tgt[i];
@@ -1340,16 +1374,16 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
     if (threadIdx.x == 0) out[0] = red[0] / (float)n3;
 }
 
-void launch_mse(const float* rgb, const float* target, long long N, float loss_scale, float* d_rgb, float* mse_out,
+void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float* d_rgb, float* mse_out,
                 hipStream_t s) {
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, rgb, target, N * 3, loss_scale, d_rgb, mse_out);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, rgb, target, N * 3, st, d_rgb, mse_out);
 }
 
 // LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
 // as one entry of either blob is Inf/NaN (the caller sets it to 1 first).
-__global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, float inv_scale,
-                                     int* __restrict__ all_finite) {
+__global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, OptState* __restrict__ st) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float inv_scale = st->inv_scale;
     bool bad = false;
     if (i < n) {
         const float a = ga[i] * inv_scale;
@@ -1361,12 +1395,11 @@ __global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__
             bad |= !(fabsf(b) <= 3.0e38f);
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) *all_finite = 0;
+    if (__any(bad) && (threadIdx.x & 63) == 0) st->finite = 0;
 }
 
-void launch_unscale_check(float* ga, float* gb, size_t n, float inv_scale, int* all_finite, hipStream_t s) {
-    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, inv_scale,
-                       all_finite);
+void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStream_t s) {
+    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, st);
 }
 
 // ------------------------------------------------------------------------------------------------
