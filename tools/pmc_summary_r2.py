@@ -23,7 +23,9 @@ KINDS = {  # tag -> [(kernel-name substring, label)]
               ("mlp_bwd_f16_dx_kernel", "mixed_float16 policy: mlp_bwd_f16_dx_kernel (single-pass backward chain, fine pass)"),
               ("mlp_bwd_f16_kernel", "mixed_float16 policy: mlp_bwd_f16_kernel (single-pass backward chain, coarse pass)"),
               ("gemm_atb_f16_kernel<256>", "mixed_float16 policy: gemm_atb_f16<256> (weight gradient on fp16 rows, one pass)"),
-              ("head_wgrad_rows_kernel", "mixed_float16 policy: head_wgrad_rows (the two heads' weight gradients)")],
+              ("gemm_atb_f16_kernel<128>", "mixed_float16 policy: gemm_atb_f16<128> (weight gradient of layer 8)"),
+              ("head_wgrad_frag_kernel", "mixed_float16 policy: head_wgrad_frag (the two heads' weight gradients)"),
+              ("reduce_grad_vec_kernel", "mixed_float16 policy: reduce_grad_vec (sum of the 256 row-slab partials of a wide layer)")],
 }
 
 
