@@ -132,7 +132,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     float pc = 0.f;                          // packed-scale value waiting for its pair
     (void)q0; (void)q1; (void)q2; (void)pc;
     // true-scale store of registers r-3..r (r & 3 == 3) of a tile whose 32 rows start at column c0 of `base`
-    // fragc: `base` is a fragment-major buffer (train_kernels.h::frag_index: a feature offset c, c % 8 == 0, is the
+    // fragc: `base` is a fragment-major buffer (frag_layout.h::frag_index: a feature offset c, c % 8 == 0, is the
     // element offset 32 c from the lane's base) -- D and dx both are
     auto store4 = [&](float* base, int c0, int r, float v, auto fragc) {
         f32x4 o;

@@ -34,7 +34,7 @@ __device__ unsigned long long g_stamps_h[16];
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
 // STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
 // of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store, in the
-// FRAGMENT-MAJOR layout of train_kernels.h::frag_index (a store instruction writes 1 KiB / 512 B of consecutive bytes).
+// FRAGMENT-MAJOR layout of frag_layout.h::frag_index (a store instruction writes 1 KiB / 512 B of consecutive bytes).
 // FAST + STASH (the mixed_float16 policy's forward) writes the stash in fp16 -- the very dwords it packs as the next
 // layer's operand, four consecutive features per 8-byte store -- and st_prev / st_cur then point at fp16 rows.
 // It also records the LeakyReLU' masks the fused backward (mlp_bwd_f16x3.hip) multiplies by: one bit per activation
@@ -413,7 +413,7 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             else {
                 // row offset in elements (st_ld[l] elements per row): fp32 elements, or fp16 ones under FAST (the pointer
                 // arithmetic below is in floats, so halve it there)
-                // fragment-major rows (train_kernels.h::frag_index): the wave's 32 samples are one block, lane (h, j) owns
+                // fragment-major rows (frag_layout.h::frag_index): the wave's 32 samples are one block, lane (h, j) owns
                 // the 4-element slot h * 32 + j of every 8-feature group; a feature offset c (c % 8 == 0) is 32 c elements
                 const long long row0 = a.diag_wrap ? (long long)(blockIdx.x & 63) * 128 + wave * 32 : tile * 128 + wave * 32;
                 const long long off = row0 * (long long)a.st_ld[l] + (h * 32 + j) * 4;

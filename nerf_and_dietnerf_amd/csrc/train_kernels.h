@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "frag_layout.h"
 
 namespace nerf {
 
@@ -14,16 +15,7 @@ constexpr int kDirPad = 32;
 constexpr int kTrainSplits = 128;   // row slabs of the weight-gradient reduction
 constexpr int kTrainSplitsWide = 256;   // ... with the 256 x 256 tile (one tile per slab for a 256 x 256 layer)
 
-// Fragment-major activation / gradient buffers (the fused training kernels): inside every block of 32 rows the elements
-// are ordered [feature / 8][(feature / 4) % 2][row % 32][feature % 4] -- the order in which the 64 lanes of a wave hold a
-// 32-sample x 8-feature accumulator slice (lane = 32 * half + sample, four consecutive features per lane).  One store
-// instruction of the fused forward / backward kernels then writes 512 (fp16) or 1024 (fp32) contiguous bytes instead of
-// 32 pieces of 16 / 32 bytes on 32 different rows, and the weight-gradient GEMMs read a thread's 4 x 4 block as 32 / 64
-// contiguous bytes.  Same footprint as row-major with pitch ld (ld % 8 == 0); a column offset c (c % 8 == 0) is the
-// pointer offset 32 * c.
-__host__ __device__ inline long long frag_index(long long row, int col, int ld) {
-    return (row >> 5) * 32 * ld + (((col >> 3) * 64 + ((col >> 2) & 1) * 32 + (int)(row & 31)) * 4 + (col & 3));
-}
+// Fragment-major activation / gradient buffers (the fused training kernels): frag_layout.h::frag_index
 
 enum { EPI_FWD_LEAKY = 0, EPI_FWD_LINEAR = 1, EPI_BWD_MASK = 2, EPI_BWD_PLAIN = 3 };
 

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
     const int col0 = on ? (isG ? nb : kb) + 4 * cg : 0;
-    // fragment-major operands (train_kernels.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive floats
+    // fragment-major operands (frag_layout.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive floats
     const int rs = g.frag ? 4 : ld;                                   // floats between two of its rows
     const float* src = (isG ? g.G : g.A) + (g.frag ? frag_index(ms + 4 * rg, col0, ld) : (ms + 4 * rg) * ld + col0);
     const float mul = isG ? gscale : 1.0f;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
     const int col = on ? (isG ? nb : kb) + 4 * cg : 0;
-    // fragment-major operands (train_kernels.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive elements
+    // fragment-major operands (frag_layout.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive elements
     const int rs = g.frag ? 4 : ld;                                   // elements between two of its rows
     const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) +
                           (g.frag ? frag_index(ms + 4 * rg, col, ld) : (ms + 4 * rg) * ld + col);
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void head_wgrad_rows_kernel(const GemmAtb g) {
     }
 }
 
-// Fragment-major A (the fused trainer, train_kernels.h::frag_index): for one column quad the 32 rows of a block are 256
+// Fragment-major A (the fused trainer, frag_layout.h::frag_index): for one column quad the 32 rows of a block are 256
 // (fp16) or 512 (fp32) consecutive bytes.  Eight neighbouring lanes share a column quad and take four rows each -- a
 // whole block per round, one contiguous run per quad -- over all the slab's blocks; their sums meet in a fixed shuffle
 // butterfly (no LDS), lane 0 of the eight writes the 4 x 4 results.  A workgroup covers 32 quads per pass over the slab.
@@ -1540,7 +1540,7 @@ __global__ void pe_bwd_kernel(const float* __restrict__ dA0, const float* __rest
                         __fadd_rn(oo.z, __fmul_rn(dd.z, zz))};
     const float dv[3] = {dd.x, dd.y, dd.z};
     // the encoding gradient may come in two parts (fused backward: through layer 4 and through layer 0)
-    // frag: the (Mp, 64) rows are fragment-major (train_kernels.h::frag_index; written by the fused backward chain):
+    // frag: the (Mp, 64) rows are fragment-major (frag_layout.h::frag_index; written by the fused backward chain):
     // neighbouring threads read neighbouring 16-byte slots
     float g[36];
 #pragma unroll
