@@ -596,6 +596,31 @@ def test_dietnerf_consistency_step_shape(oracle, golden_ckpt, capsys):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(37, 20, 100), (42, 70, 130), (130, 2, 3)])
+def test_gradients_at_ragged_shapes(oracle, golden_ckpt, shape, capsys):
+    """Ray and sample counts that fit none of the kernels' granularities -- rays not a multiple of the four per
+    compositing workgroup, sample counts that end inside a 64-lane chunk (20, 100, 70, 130) or are tiny (2, 3), row
+    counts that are not whole 32-row blocks of the fragment-major buffers or whole 128-row tiles -- against the float64
+    autograd oracle, sampler term on, smooth alpha = 1 network.  Bar 5e-4 of max|g| (2e-4 at the reference's sample
+    counts: a 20-bin coarse pdf leaves the inverse-CDF interpolation more intervals at its 1e-5 clamp)."""
+    from oracle import train_oracle as T
+    n, sc, sf = shape
+    p = _problem(oracle, golden_ckpt, n=n, sc=sc, sf=sf, seed=11)
+    ctx = _ctx(p, leaky_relu_alpha=1.0)
+    ctx.train_begin(5e-4, sampler_gradient=True)
+    m, gc, gf = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
+                          sampler_grad=True, alpha=1.0)
+    ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
+    cc, cf = _cos(gc, r["grad_coarse"]), _cos(gf, r["grad_fine"])
+    with capsys.disabled():
+        print(f"\n[{n} rays x ({sc} + {sf}), alpha 1.0, sampler term on] vs float64 autograd: max gradient difference / "
+              f"max|g| coarse {ec:.2e}, fine {ef:.2e}; cosine {cc:.7f}, {cf:.7f}")
+    assert abs(m["loss"] - r["loss"]) <= 2e-6 * r["loss"]
+    assert ec <= 5e-4 and cc > 0.999999 and ef <= 5e-4 and cf > 0.999999
+    ctx.close()
+
+
 @pytest.mark.parametrize("alpha", [1.0, 0.05])
 def test_gradients_at_the_reference_sample_counts(oracle, golden_ckpt, alpha, capsys):
     """The float64 autograd oracle at the reference's own sample counts (64 coarse + 128 fine) on a 32-ray batch, sampler
