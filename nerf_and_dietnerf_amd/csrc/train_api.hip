@@ -59,8 +59,8 @@ struct TrainState {
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
-    // row pitch (floats) of the 256-wide / 128-wide activation and gradient buffers (NERF_TRAIN_LDH: padding them off
-    // the power of two was tried against L2-channel hot-spotting of the one-row-per-lane stores and LOST, see train_begin)
+    // elements per row of the 256-wide / 128-wide activation and gradient buffers (padded pitches were measured against
+    // L2-channel hot-spotting in round 2 and lost; the fused path's buffers are fragment-major now, frag_layout.h)
     int ldh = 256, ldh9 = 128;
     bool acc_grads = false;         // the running backward pass ADDS to the gradient blobs (nerf_train_render_gradients)
     // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients

@@ -159,6 +159,26 @@ def test_ray_marching(nerf, oracle, golden_vec):
         assert np.abs(g - r).max() <= 1e-6
 
 
+@pytest.mark.parametrize("n_samples", [1, 2, 63, 65, 130, 257])
+def test_ray_marching_ragged_sample_counts(nerf, oracle, n_samples):
+    """The one-ray-per-wavefront compositing kernel at sample counts that end inside a 64-lane chunk, span several
+    chunks, or are tiny; 37 rays (not a multiple of the four rays of a workgroup).  The transmittance is passed lane to
+    lane in the canonical order: weights and cumprod agree with the sequential oracle to the expf ulp."""
+    import nerf_and_dietnerf_amd as N
+    rng = np.random.default_rng(100 + n_samples)
+    raw = rng.normal(0.0, 2.0, size=(37, n_samples, 4)).astype(np.float32)
+    raw[3, :, 3] = 50.0                                                   # an opaque ray
+    raw[4, :, 3] = -1.0                                                   # an empty one
+    z = np.sort(rng.uniform(0.5, 2.5, size=(37, n_samples)).astype(np.float32), axis=-1)
+    got = N.ray_marching(raw, z, ctx=nerf.ctx)
+    ref = oracle.ray_marching(raw, z)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and np.isfinite(g).all()
+        assert np.abs(g - r).max() <= 1e-6
+    T = got[2]
+    assert np.all(np.diff(T, axis=-1) <= 0.0)                             # never increases -- exactly
+
+
 def test_render_rays(nerf, oracle, golden_vec):
     o, d, z = golden_vec["rays_orig"], golden_vec["rays_dirs"], golden_vec["z_coarse"]
     got = nerf.render_rays(nerf.model_coarse, o, d, z)
