@@ -70,6 +70,8 @@ __global__ void scale_kernel(float* __restrict__ x, size_t n, float s) {
 }
 
 // mean over the ranks of the ctx's communicator, in place on the ctx stream; no-op without a communicator
+int comm_world(const nerf_ctx* c) { return c->comm && c->comm->comm ? c->comm->world : 1; }
+
 int comm_allreduce_mean(nerf_ctx* c, float* buf, size_t n) {
     if (!c->comm || !c->comm->comm || c->comm->world == 1) return 0;
     NCCL_OK(g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm->comm, c->stream));

@@ -69,6 +69,7 @@ int enter(nerf_ctx* c);                             // NULL check + hipSetDevice
 void train_free(nerf_ctx* c);                       // train_api.hip: releases c->train (called by nerf_ctx_destroy)
 void comm_free(nerf_ctx* c);                        // comm_api.hip: releases c->comm (called by nerf_ctx_destroy)
 int comm_allreduce_mean(nerf_ctx* c, float* buf, size_t n);   // comm_api.hip: no-op without a communicator / one rank
+int comm_world(const nerf_ctx* c);                            // ranks of the ctx's communicator (1 without one)
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob_host);   // nerf_api.hip: pack + upload streams
 int train_on_load(nerf_ctx* c, int which);          // train_api.hip: no-op without a trainer
 int train_flush_weights(nerf_ctx* c, int which);

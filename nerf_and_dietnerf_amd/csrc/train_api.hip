@@ -931,9 +931,11 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
     for (int w = 0; w < 2; ++w)
         if (c->train->net[w].present)
             if (int r = comm_allreduce_mean(c, c->train->net[w].grad, c->train->nblob)) return r;
-    // (a non-finite shard gradient makes the all-reduced blob non-finite on every rank: ranks agree by themselves only
-    //  when the test runs after the all-reduce -- single-rank here; the data-parallel path is nerf_train_gradients +
-    //  the caller's all-reduce + nerf_train_apply, where the caller shares the verdict)
+    // a non-finite shard gradient makes the all-reduced blob non-finite on EVERY rank: the finiteness test is repeated on
+    // the reduced blobs so that all ranks reach the same verdict (drop the step, halve the scale) by themselves
+    if (c->train->mixed && comm_world(c) > 1)
+        launch_unscale_check(c->train->net[0].grad, c->train->net[1].present ? c->train->net[1].grad : nullptr,
+                             c->train->nblob, (OptState*)c->train->opt.p, c->stream, true);
     take_verdict(c);
     if (int r = apply_impl(c)) return r;                 // gated on the device by the verdict
     return read_metrics(c, fine, metrics);

@@ -1381,9 +1381,10 @@ void launch_mse(const float* rgb, const float* target, long long N, const OptSta
 
 // LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
 // as one entry of either blob is Inf/NaN (the caller sets it to 1 first).
-__global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, OptState* __restrict__ st) {
+__global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, OptState* __restrict__ st,
+                                     int check_only) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const float inv_scale = st->inv_scale;
+    const float inv_scale = check_only ? 1.0f : st->inv_scale;
     bool bad = false;
     if (i < n) {
         const float a = ga[i] * inv_scale;
@@ -1398,8 +1399,9 @@ __global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__
     if (__any(bad) && (threadIdx.x & 63) == 0) st->finite = 0;
 }
 
-void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStream_t s) {
-    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, st);
+void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStream_t s, bool check_only) {
+    hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, st,
+                       check_only ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
