@@ -505,6 +505,7 @@ class NeRF:
         self.ctx.train_begin(optimizer_lr, beta_1, beta_2, epsilon, sampler_gradient, mixed_float16, initial_loss_scale,
                              dynamic_growth_steps)
         self._train_calls = 0
+        self._mixed = bool(mixed_float16)
 
     def train_step(self, data, *, u_coarse=None, u_fine=None, seed=None, group=None) -> Dict[str, float]:
         """``data`` = (rays_orig (N,4), rays_dirs (N,4), real_rgb (N,3)) -> {"loss", "psnr_coarse"[, "psnr_fine"]}.
@@ -519,6 +520,16 @@ class NeRF:
         from .sharding import dist_world
         world = dist_world(group)
         if world == 1:
+            return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
+                                       u_fine, seed)
+        if getattr(self, "_mixed", False):
+            # loss-scaled policy: the step is dropped if ANY rank's gradients are not finite, and every rank must move its
+            # loss scale the same way -- the library's own data-parallel step (ncclAllReduce of the gradient blobs, then
+            # the finiteness test on the reduced blobs, all on the device) does that; the communicator is joined on first
+            # use through the group's store
+            if not getattr(self, "_comm_group", None) is group or not getattr(self, "_comm_ready", False):
+                self.ctx.comm_init_from_torch(group)
+                self._comm_group, self._comm_ready = group, True
             return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
                                        u_fine, seed)
         from .sharding import allreduce_mean
