@@ -392,6 +392,8 @@ def main():
                  "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                  "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
                  "loss_finite": bool(m_tr["loss"] == m_tr["loss"]),
+                 "policy": "float32 (fp32-class gradients; the figures of this level)",
+                 "ms_per_step_reference_policy": e_mx * 1e3,     # = mixed_float16_policy.ms_per_step, the policy the reference trains under
                  "mixed_float16_policy": {"ms_per_step": e_mx * 1e3, "value": n_tr / e_mx, "unit": "rays/s",
                                           "loss_scale": ls_mx[0], "steps_skipped": ls_mx[2],
                                           "note": "the reference's production policy (src/ExecutionRun.py:220-221, "
