@@ -74,7 +74,7 @@ struct MlpArgs {
     int st_ld[9];
     // ... and where the LeakyReLU' mask bits of layer l's output go: one uint4 per (row, lane half), see mlp_f16x3.hip
     uint32_t* mask_ptr[9];
-    int diag_wrap;          // diagnostic only (NERF_DIAG_STASH_WRAP=1): all stash rows of a workgroup land on 8 rows (L2-resident)
+    int diag_wrap;          // diagnostic only (NERF_DIAG_STASH_WRAP=1): every workgroup's stash rows land in the first 8192 rows (cache-resident)
 };
 
 // mlp_fp32.hip

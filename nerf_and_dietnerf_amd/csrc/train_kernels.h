@@ -51,7 +51,7 @@ struct GemmAtb {
     long long M; int rows_per_split;    // multiple of 16
     const unsigned* gmax;               // split-fp16 variant: bits of max|G| (written by G's producer); G is scaled to fp16 range
     int a_f16;                          // head_wgrad: A holds fp16 elements (lda in halfs); gemm_atb_f16: both operands do
-    int frag;                           // A and G (not the heads' 4-wide G) are fragment-major (frag_index below); rows_per_split % 32 == 0
+    int frag;                           // A and G (not the heads' 4-wide G) are fragment-major (frag_layout.h::frag_index); rows_per_split % 32 == 0
 };
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
