@@ -271,7 +271,7 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
             a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i];
             a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
         }
-        { const char* dw = getenv("NERF_DIAG_STASH_WRAP"); a.diag_wrap = dw && dw[0] == '1'; }   // timing diagnostic: wrong results
+        { const char* dw = getenv("NERF_DIAG_STASH_WRAP"); a.diag_wrap = dw && dw[0] == '1' && d.Mp >= 8192; }   // timing diagnostic: wrong results
         launch_mlp_f16x3_stash(a, c->num_cus, c->stream, t->mixed);
     } else {
         forward_layers(c, n, p, d.Mp, raw);
