@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NERF_MI355_LIB") or os.path.join(_HERE, "lib", "libne
 NERF_NET_COARSE, NERF_NET_FINE = 0, 1
 NERF_MEM_HOST, NERF_MEM_DEVICE = 0, 1
 NERF_PRECISION_FP32, NERF_PRECISION_F16X3, NERF_PRECISION_F16 = 0, 1, 2
-NERF_ABI_VERSION = 2
+NERF_ABI_VERSION = 3
 
 
 class NerfConfig(C.Structure):
@@ -75,6 +75,7 @@ SYMBOLS = [
     ("nerf_train_apply", C.c_int, [_P, _P, _P, C.c_int]),
     ("nerf_train_render_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, _I32, _P, _P, _P,
                                               C.c_int]),
+    ("nerf_train_get_gradients", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_get_weights", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_ctx_enable_timing", C.c_int, [_P, C.c_int]),
     ("nerf_ctx_read_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),

@@ -5,6 +5,7 @@
 // libnerf_mi355.so carry no dependency on it; in a process that already holds a librccl (PyTorch-ROCm bundles one) that
 // copy is reused.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <rccl/rccl.h>   // types and enums only: every entry point is resolved with dlsym
 
@@ -29,6 +30,13 @@ int load_rccl() {
     if (g_rccl.lib) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so"};
     void* h = nullptr;
+    // NERF_RCCL_LIB: path of the library that provides the six nccl* entry points used here (a site's own RCCL build;
+    // the tests' two-ranks-on-one-GPU stand-in, tests/stub_rccl.c).  It changes who moves the bytes, never the result.
+    const char* override_path = getenv("NERF_RCCL_LIB");
+    if (override_path && override_path[0]) {
+        h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail("NERF_RCCL_LIB=%s cannot be loaded: %s", override_path, dlerror());
+    }
     for (const char* n : names)
         if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // a copy this process already holds (e.g. torch's)
     for (const char* n : names)

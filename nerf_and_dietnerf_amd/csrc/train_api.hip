@@ -66,7 +66,6 @@ struct TrainState {
     // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients
     // and the dynamic loss scale of Keras' LossScaleOptimizer
     bool mixed = false;
-    bool last_finite = true;        // host copy of the latest verdict, read back only by the gradients / apply split API
     DevBuf opt;                     // OptState (train_kernels.h): loss scale, verdicts, Adam iteration count -- on the device
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
     TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
@@ -189,8 +188,8 @@ struct PassDims { long long N; int S; long long M, Mp; };
 
 int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     const size_t f = sizeof(float);
-    // the mixed_float16 policy keeps activations and pre-activation gradients in fp16 (same element pitches); sized for
-    // fp32 anyway: the buffers are shared with later fp32-policy trainers of the same context only after train_free
+    // the mixed_float16 policy keeps activations and pre-activation gradients in fp16 (same element pitches, half the
+    // bytes); the buffers are grow-only and are released by train_free before a trainer of the other policy starts
     const size_t ea = c->train && c->train->mixed && c->train->training ? 2 : f;
     int r = 0;
     r |= ensure(c, p.C4, d.Mp * kLdC4 * ea);
@@ -271,7 +270,9 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
             a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i];
             a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
         }
-        { const char* dw = getenv("NERF_DIAG_STASH_WRAP"); a.diag_wrap = dw && dw[0] == '1' && d.Mp >= 8192; }   // timing diagnostic: wrong results
+#ifdef NERF_DIAG_STASH_WRAP   // diagnostic BUILD only (make EXTRA=-DNERF_DIAG_STASH_WRAP): timing without HBM stores, wrong results
+        a.diag_wrap = d.Mp >= 8192;
+#endif
         launch_mlp_f16x3_stash(a, c->num_cus, c->stream, t->mixed);
     } else {
         forward_layers(c, n, p, d.Mp, raw);
@@ -485,6 +486,11 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     float* scal = (float*)t->scal.p;
     float* Graw = (float*)t->Graw.p;
     float* d_rgb = (float*)t->d_rgb.p;
+    // the finiteness flag collects over ONE gradient computation: gradients that were computed and never applied
+    // (nerf_train_gradients without nerf_train_apply) must not decide the next step's verdict
+    if (t->mixed) launch_opt_begin((OptState*)t->opt.p, c->stream);
+    if (!fine && t->net[1].present)   // a skipped fine pass must not move the fine network
+        HIP_OK(hipMemsetAsync(t->net[1].grad, 0, t->nblob * f, c->stream));
 
     // coarse forward (src/NeRF.py:146-151)
     TPass& pc = t->pass[0];
@@ -526,17 +532,15 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
 // The verdict of the gradients just computed, on the device: loss-scale bookkeeping (mixed_float16 policy: Keras 2.7
 // LossScaleOptimizer -- halve on a non-finite step, double after `growth` finite ones) and the flag that lets this step's
 // Adam launches through.  No host round trip: nerf_train_step keeps enqueuing.
-void take_verdict(nerf_ctx* c) { launch_opt_verdict((OptState*)c->train->opt.p, c->stream); }
-
-// ... and its host copy, for the gradients / apply split API whose caller decides between the two calls
-int read_verdict(nerf_ctx* c) {
+// The verdict is taken on the blobs that are about to be APPLIED -- after a gradient all-reduce (the library's own, or the
+// caller's between nerf_train_gradients and nerf_train_apply) those are the reduced blobs, on which every rank reaches
+// the same verdict by itself: a non-finite shard makes the sum non-finite everywhere.
+void take_verdict(nerf_ctx* c, bool recheck) {
     TrainState* t = c->train;
-    if (!t->mixed) { t->last_finite = true; return 0; }     // the float32 policy never drops a step
-    OptState h;
-    HIP_OK(hipMemcpyAsync(&h, t->opt.p, sizeof(OptState), hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    t->last_finite = h.apply_ok != 0;
-    return 0;
+    if (t->mixed && recheck)
+        launch_unscale_check(t->net[0].grad, t->net[1].present ? t->net[1].grad : nullptr, t->nblob, (OptState*)t->opt.p,
+                             c->stream, true);
+    launch_opt_verdict((OptState*)t->opt.p, c->stream);
 }
 
 // Backward through NeRF.render() itself (src/NeRF.py:109-134), the graph DietNeRF's consistency loss differentiates
@@ -788,7 +792,6 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
         if (int r = ensure(c, t->opt, sizeof(OptState))) { train_free(c); return r; }
         HIP_OK(hipMemcpy(t->opt.p, &h, sizeof(OptState), hipMemcpyHostToDevice));
     }
-    t->last_finite = true;
     // forward on the fused kernel unless the network has no fused kernel (xyz-only) or NERF_TRAIN_FORWARD=gemm asks
     // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
     const char* fw = getenv("NERF_TRAIN_FORWARD");
@@ -871,8 +874,8 @@ int nerf_train_gradients(nerf_ctx* c, const float* rays_orig, const float* rays_
     if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
     TrainState* t = c->train;
     const bool fine = Sf > 0 && t->net[1].present;
-    take_verdict(c);
-    if (int r = read_verdict(c)) return r;               // mixed_float16: nerf_train_apply skips a non-finite step
+    // (mixed_float16: the gradients come back unscaled; the skip-or-apply verdict and the loss-scale move belong to
+    // nerf_train_apply, which tests the blobs it is given)
     const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
     if (grad_fine) {
@@ -914,7 +917,9 @@ int nerf_train_apply(nerf_ctx* c, const float* grad_coarse, const float* grad_fi
         HIP_OK(hipMemcpyAsync(t->net[1].grad, grad_fine, t->nblob * sizeof(float), kind, c->stream));
     }
     if (mem == NERF_MEM_HOST && (grad_coarse || grad_fine)) HIP_OK(hipStreamSynchronize(c->stream));
-    if (t->mixed && !t->last_finite) return 0;          // LossScaleOptimizer.apply_gradients skips this step
+    // LossScaleOptimizer.apply_gradients: test what is about to be applied (the caller's all-reduced blobs, or the ctx's
+    // own after nerf_train_gradients [+ nerf_train_render_gradients]); a non-finite step is skipped on the device
+    take_verdict(c, true);
     return apply_impl(c);
 }
 
@@ -924,8 +929,6 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
     ENTER(c);
     if (int r = gradients_impl(c, rays_orig, rays_dirs, target_rgb, N, Sc, Sf, u_coarse, u_fine, seed, mem)) return r;
     const bool fine = Sf > 0 && c->train->net[1].present;
-    if (!fine && c->train->net[1].present)   // a skipped fine pass must not move the fine network
-        HIP_OK(hipMemsetAsync(c->train->net[1].grad, 0, c->train->nblob * sizeof(float), c->stream));
     // data-parallel: with a communicator (nerf_comm_init) every rank passes its shard of the batch and the gradient
     // blobs are averaged here, one all-reduce each, before the identical Adam update
     for (int w = 0; w < 2; ++w)
@@ -933,12 +936,24 @@ int nerf_train_step(nerf_ctx* c, const float* rays_orig, const float* rays_dirs,
             if (int r = comm_allreduce_mean(c, c->train->net[w].grad, c->train->nblob)) return r;
     // a non-finite shard gradient makes the all-reduced blob non-finite on EVERY rank: the finiteness test is repeated on
     // the reduced blobs so that all ranks reach the same verdict (drop the step, halve the scale) by themselves
-    if (c->train->mixed && comm_world(c) > 1)
-        launch_unscale_check(c->train->net[0].grad, c->train->net[1].present ? c->train->net[1].grad : nullptr,
-                             c->train->nblob, (OptState*)c->train->opt.p, c->stream, true);
-    take_verdict(c);
+    // (repeated whenever the ctx has a communicator, one rank included: one small kernel)
+    take_verdict(c, c->comm != nullptr);
     if (int r = apply_impl(c)) return r;                 // gated on the device by the verdict
     return read_metrics(c, fine, metrics);
+}
+
+int nerf_train_get_gradients(nerf_ctx* c, int which, float* blob, size_t n_floats, int mem) {
+    ENTER(c);
+    TrainState* t = c->train;
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
+    if (!blob) return fail("blob is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail("which must be 0 (coarse) or 1 (fine)");
+    if (!t->net[which].present) return fail("network %d has no weights loaded", which);
+    if (n_floats != t->nblob) return fail("gradient blob has %zu floats, expected %zu", n_floats, t->nblob);
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_OK(hipMemcpyAsync(blob, t->net[which].grad, t->nblob * sizeof(float), kind, c->stream));
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int nerf_get_weights(nerf_ctx* c, int which, float* blob, size_t n_floats, int mem) {

@@ -101,6 +101,7 @@ void launch_mse(const float* rgb, const float* target, long long N, const OptSta
                 hipStream_t s);         // d_rgb carries st->scale (LossScaleOptimizer.get_scaled_loss)
 void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, OptState* st, hipStream_t s,
                           bool check_only = false);    // check_only: finiteness test alone (after a gradient all-reduce)
+void launch_opt_begin(OptState* st, hipStream_t s);                            // before a gradient computation: finite = 1
 void launch_opt_verdict(OptState* st, hipStream_t s);                          // after the gradients: scale bookkeeping, apply_ok
 void launch_opt_tick(OptState* st, float beta1, float beta2, hipStream_t s);   // after Adam: iterations, adam_corr
 void launch_composite_bwd(const float* raw, const float* z, const float* T, long long N, int S, const float* d_rgb,

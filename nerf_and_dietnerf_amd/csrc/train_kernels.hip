@@ -1264,6 +1264,9 @@ __global__ void opt_verdict_kernel(OptState* st) {
     st->finite = 1;
 }
 
+__global__ void opt_begin_kernel(OptState* st) { st->finite = 1; }
+void launch_opt_begin(OptState* st, hipStream_t s) { hipLaunchKernelGGL(opt_begin_kernel, dim3(1), dim3(1), 0, s, st); }
+
 void launch_opt_verdict(OptState* st, hipStream_t s) { hipLaunchKernelGGL(opt_verdict_kernel, dim3(1), dim3(1), 0, s, st); }
 
 // One thread, after the Adam launches of a step: count the update and prepare the next bias correction (in double)

@@ -106,6 +106,7 @@ class Context:
         self.h = h
         self.loaded = [False, False]
         self._stream = None
+        self.comm_world = 0          # ranks of this ctx's in-library communicator (0 = none)
 
     def close(self):
         if getattr(self, "h", None):
@@ -168,17 +169,21 @@ class Context:
 
     def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
         buf = C.create_string_buffer(bytes(unique_id), 128)
+        self.comm_world = 0
         _lib.check(self.lib.nerf_comm_init(self.h, buf, rank, world))
+        self.comm_world = world
 
     def comm_init_from_torch(self, group=None) -> None:
-        """Join the ranks of an initialised torch.distributed group (the id travels through its store)."""
+        """Join the ranks of an initialised torch.distributed group: rank 0 draws the id, the group (any backend --
+        it only carries 128 bytes) hands it to the others.  One process per GPU: RCCL refuses two ranks on a device."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [self.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self.comm_init(box[0], rank, world)
 
     def comm_destroy(self) -> None:
+        self.comm_world = 0
         _lib.check(self.lib.nerf_comm_destroy(self.h))
 
     def render_image_sharded(self, c2w, fov, h, w, batch, n_c, n_f, seed=0, device_out=False):
@@ -267,6 +272,12 @@ class Context:
         arr = self._arrays(grad_coarse, grad_fine)
         n = self.blob_size()
         _lib.check(self.lib.nerf_train_apply(self.h, arr.inp(grad_coarse, (n,)), arr.inp(grad_fine, (n,)), arr.mem))
+
+    def train_get_gradients(self, which: int) -> np.ndarray:
+        """The gradient blob the ctx holds now (after a data-parallel ``train_step``: the all-reduced mean)."""
+        out = np.empty(self.blob_size(), np.float32)
+        _lib.check(self.lib.nerf_train_get_gradients(self.h, which, out.ctypes.data, out.size, NERF_MEM_HOST))
+        return out
 
     def get_weights(self, which: int) -> np.ndarray:
         """Current weights as a flat blob in Keras ``get_weights()`` order."""
@@ -511,7 +522,11 @@ class NeRF:
         """``data`` = (rays_orig (N,4), rays_dirs (N,4), real_rgb (N,3)) -> {"loss", "psnr_coarse"[, "psnr_fine"]}.
 
         Under an initialised torch.distributed ``group`` every rank passes its own shard of the batch; the
-        gradient blobs are averaged with one all-reduce each (RCCL) before the identical Adam update."""
+        gradient blobs are averaged with one all-reduce each before the identical Adam update: inside the library
+        (ncclAllReduce on the ctx stream) when the ctx has joined a communicator of the group's size
+        (``ctx.comm_init_from_torch(group)``), otherwise through the group itself (RCCL under nccl; gloo stages through the
+        host).  Under mixed_float16 both ways test the REDUCED blobs, so every rank skips the same steps and moves its loss
+        scale alike (src/NeRF.py:159-163 on each replica)."""
         rays_orig, rays_dirs, real_rgb = data
         n_f = self.n_render_samples_fine if self.model_fine else 0
         if seed is None:
@@ -519,19 +534,11 @@ class NeRF:
         self._train_calls += 1
         from .sharding import dist_world
         world = dist_world(group)
-        if world == 1:
+        if world == 1 or self.ctx.comm_world == world:
             return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
                                        u_fine, seed)
-        if getattr(self, "_mixed", False):
-            # loss-scaled policy: the step is dropped if ANY rank's gradients are not finite, and every rank must move its
-            # loss scale the same way -- the library's own data-parallel step (ncclAllReduce of the gradient blobs, then
-            # the finiteness test on the reduced blobs, all on the device) does that; the communicator is joined on first
-            # use through the group's store
-            if not getattr(self, "_comm_group", None) is group or not getattr(self, "_comm_ready", False):
-                self.ctx.comm_init_from_torch(group)
-                self._comm_group, self._comm_ready = group, True
-            return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
-                                       u_fine, seed)
+        if self.ctx.comm_world:
+            raise RuntimeError(f"the context's communicator has {self.ctx.comm_world} ranks, the group {world}")
         from .sharding import allreduce_mean
         metrics, gc, gf = self.ctx.train_gradients(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f,
                                                    u_coarse, u_fine, seed)

@@ -451,6 +451,57 @@ def test_train_step_with_one_rank_communicator(oracle, golden_ckpt):
     assert res[0][0] == res[1][0]
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
+    # mixed_float16 under the communicator: the finiteness test repeated on the (here: trivially) reduced blobs runs
+    # whenever a communicator exists -- an infinite target is skipped, the scale halves, the weights stay
+    bad = p["tgt"].copy()
+    bad[0, 0] = np.inf
+    ctx = _ctx(p)
+    ctx.comm_init(N.Context.comm_unique_id(), 0, 1)
+    ctx.train_begin(5e-4, mixed_float16=True, initial_loss_scale=1024.0)
+    ctx.train_step(p["o"], p["d"], bad, p["sc"], p["sf"], p["u_c"], p["u_f"])
+    assert ctx.train_loss_scale() == (512.0, 0, 1)
+    np.testing.assert_array_equal(ctx.get_weights(0), p["bc"])
+    ctx.train_step(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    assert ctx.train_loss_scale() == (512.0, 1, 1)
+    ctx.close()
+
+
+def test_mixed_policy_split_api_takes_its_verdict_on_the_applied_blobs(oracle, golden_ckpt):
+    """nerf_train_gradients + nerf_train_apply under mixed_float16 (the data-parallel flow of include/nerf_mi355.h: the
+    caller all-reduces between the two).  The verdict belongs to the blobs that are APPLIED: finite local gradients
+    followed by a non-finite (all-reduced) blob are skipped with a halved scale; gradients computed and never applied
+    do not leak their verdict into the next step; the ctx's own blobs behave like nerf_train_step."""
+    p = _problem(oracle, golden_ckpt, n=32, sc=8, sf=8, seed=14)
+    args = (p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    bad = p["tgt"].copy()
+    bad[0, 0] = np.inf
+    ctx = _ctx(p)
+    ctx.train_begin(5e-4, mixed_float16=True, initial_loss_scale=1024.0)
+    _, gc, gf = ctx.train_gradients(*args)
+    assert np.isfinite(gc).all() and ctx.train_loss_scale() == (1024.0, 0, 0)      # no verdict yet
+    poisoned = gc.copy()
+    poisoned[5] = np.nan                                                           # "another rank's shard overflowed"
+    ctx.train_apply(poisoned, gf)
+    assert ctx.train_loss_scale() == (512.0, 0, 1)
+    np.testing.assert_array_equal(ctx.get_weights(0), p["bc"])
+    np.testing.assert_array_equal(ctx.get_weights(1), p["bf"])
+    ctx.train_gradients(p["o"], p["d"], bad, p["sc"], p["sf"], p["u_c"], p["u_f"])  # non-finite, never applied
+    _, gc, gf = ctx.train_gradients(*args)
+    ctx.train_apply(gc, gf)
+    assert ctx.train_loss_scale() == (512.0, 1, 1)
+    w1 = ctx.get_weights(0)
+    assert np.isfinite(w1).all() and not np.array_equal(w1, p["bc"])
+    ctx.train_gradients(p["o"], p["d"], bad, p["sc"], p["sf"], p["u_c"], p["u_f"])
+    ctx.train_apply()                                                               # the ctx's own (non-finite) blobs
+    assert ctx.train_loss_scale() == (256.0, 1, 2)
+    np.testing.assert_array_equal(ctx.get_weights(0), w1)
+    # the same two finite steps through nerf_train_step give the same weights as gradients + apply
+    ctx2 = _ctx(p)
+    ctx2.train_begin(5e-4, mixed_float16=True, initial_loss_scale=512.0)
+    ctx2.train_step(*args)
+    np.testing.assert_array_equal(ctx2.get_weights(0), w1)
+    ctx.close()
+    ctx2.close()
 
 
 def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, capsys):
