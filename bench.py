@@ -275,7 +275,7 @@ def main():
         roofline of the fused kernel from the library's own HIP events."""
         mdl.ctx.set_precision(precision)
         f = lambda sd: mdl.render_image(pose, fov, h, w, batch_size_input=batch, n_render_samples_c=sc,   # noqa: E731
-                                        n_render_samples_f=sf, seed=sd, device_out=True, rgb_only=True)[0]
+                                        n_render_samples_f=sf, seed=sd, device_out=True, rgb_only=True, honor_batch=True)[0]
         f(0)
         sync()
         mdl.ctx.enable_timing(True)

@@ -127,11 +127,19 @@ int nerf_render(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, i
                 int64_t ray_base, const nerf_outputs* outs, int mem);
 /* NeRF.render_image, src/NeRF.py:190-246, for the ray slab [ray_begin, ray_begin+ray_count) of the
  * row-major H*W image (ray_count <= 0 = whole image).  Outputs are slab-sized.  batch = rays per
- * internal pass (0 = library default); results do not depend on it.  u_* index by GLOBAL ray. */
+ * internal pass (0 = library default: the whole slab up to 262144 rays; a quarter of it when per-sample outputs go to
+ * host memory, so that copies overlap compute); results do not depend on it.  u_* index by GLOBAL ray. */
 int nerf_render_image(nerf_ctx* ctx, const float* c2w, float fov, int32_t H, int32_t W,
                       int64_t ray_begin, int64_t ray_count, int64_t batch, int32_t Sc, int32_t Sf,
                       const float* u_coarse, const float* u_fine, uint64_t seed,
                       const nerf_outputs* outs, int mem);
+
+/* ABI 3: page-locked (pinned) host memory for the buffers of NERF_MEM_HOST calls.  Any host memory works; with
+ * buffers from nerf_host_alloc the outputs of nerf_render_image leave the device by DMA on a second stream WHILE the
+ * next batch of rays computes (the reference concatenates its per-batch results at the end, src/NeRF.py:226-237), and
+ * the host-memory entry point runs at the device-resident rate.  Not tied to a ctx; usable from any GPU of the node. */
+int nerf_host_alloc(size_t bytes, void** out);
+int nerf_host_free(void* p);
 
 /* ---- multi-GPU assembly from C ------------------------------------------
  * One process (or thread + ctx) per GPU.  Rank 0 obtains an id and hands it to the others by any means (file, MPI,

@@ -64,7 +64,9 @@ def attach(model, device=0, precision="fp32", to_tensor=None, context_factory=No
         n_c, n_f = _counts(n_render_samples_c, n_render_samples_f)
         batch = batch_size_input if batch_size_input else model.batch_size_render
         assert batch > 0                                                # src/UtilsNRF.py:25
-        outs = ctx.render_image(np.asarray(c2w, np.float32), float(fov), h, w, batch, n_c, n_f, seed=seed_source())
+        # the reference's batch is a TensorFlow memory knob; results here do not depend on it, so the library picks its
+        # own (0): the whole slab per pass, or quarters when per-sample outputs are copied out beside the compute
+        outs = ctx.render_image(np.asarray(c2w, np.float32), float(fov), h, w, 0, n_c, n_f, seed=seed_source())
         return tuple(to_tensor(o) for o in outs)                        # shapes of src/NeRF.py:239-244
 
     model.render, model.render_image = render, render_image

@@ -61,6 +61,8 @@ SYMBOLS = [
     ("nerf_render", C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, C.POINTER(NerfOutputs), C.c_int]),
     ("nerf_render_image", C.c_int, [_P, _P, _F, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P, _P, _U64,
                                     C.POINTER(NerfOutputs), C.c_int]),
+    ("nerf_host_alloc", C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    ("nerf_host_free", C.c_int, [_P]),
     ("nerf_comm_unique_id", C.c_int, [_P]),
     ("nerf_comm_init", C.c_int, [_P, _P, _I32, _I32]),
     ("nerf_comm_destroy", C.c_int, [_P]),

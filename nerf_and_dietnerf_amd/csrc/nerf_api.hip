@@ -205,6 +205,34 @@ int copy_back_outputs(nerf_ctx* c, const nerf_outputs* host, const nerf_outputs*
     return 0;
 }
 
+// Host-memory render_image: the rows [off, off + n) of every requested output leave for the host on the ctx's COPY stream
+// as soon as the batch that produced them is done (event), while the next batch computes on the ctx stream.  With
+// page-locked destinations (nerf_host_alloc) the copies are DMA transfers that run beside the kernels; pageable
+// destinations work too (the runtime stages them) but serialise.
+int copy_back_batch(nerf_ctx* c, const nerf_outputs* host, const nerf_outputs* dev, long long off, long long n, int S,
+                    size_t batch_index) {
+    if (!c->copy_stream) HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    constexpr size_t kRing = 64;
+    if (c->copy_ev.size() < kRing) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->copy_ev.push_back(e);
+    }
+    hipEvent_t ev = c->copy_ev[batch_index % c->copy_ev.size()];
+    HIP_OK(hipEventRecord(ev, c->stream));
+    HIP_OK(hipStreamWaitEvent(c->copy_stream, ev, 0));
+    const OutSizes sz = out_sizes(S);
+    nerf_outputs h = host ? *host : nerf_outputs{};
+    nerf_outputs d = *dev;
+    for (int i = 0; i < 7; ++i) {
+        float* hp = *out_ptrs(h, i);
+        if (!hp) continue;
+        HIP_OK(hipMemcpyAsync(hp + sz.per_ray[i] * off, *out_ptrs(d, i) + sz.per_ray[i] * off,
+                              sz.per_ray[i] * n * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    return 0;
+}
+
 // render_rays on device pointers
 int dev_render_rays(nerf_ctx* c, int which, const float* o, const float* d, const float* z, long long N, int S,
                     const nerf_outputs& outs) {
@@ -307,6 +335,8 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         if (n.cst_h) (void)hipFree(n.cst_h);
     }
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (hipEvent_t e : c->copy_ev) (void)hipEventDestroy(e);
     comm_free(c);
     train_free(c);
     if (c->nonfinite) (void)hipFree(c->nonfinite);
@@ -542,7 +572,13 @@ int nerf_render_image(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32
     const int S = fine ? Sc + Sf : Sc;
     if (fine && sample_pdf_lds_bytes(Sc, Sf) > 64 * 1024) return fail("Sc=%d Sf=%d exceeds the sampler's LDS budget", Sc, Sf);
     const long long N = ray_count;
-    if (batch == 0) batch = 1 << 18;
+    if (batch == 0) {
+        batch = 1 << 18;
+        // host destinations with per-sample outputs (up to 5.4 KB per ray): four batches per slab so that the device-to-host
+        // copies of one batch run under the next batch's kernels (results do not depend on the batch)
+        const bool per_sample = outs->weights || outs->cumprod || outs->alpha || outs->rgb_samples || outs->z;
+        if (mem == NERF_MEM_HOST && per_sample && N >= 32768) batch = ((N + 3) / 4 + 127) / 128 * 128;
+    }
     // rays of the slab (origins are the broadcast translation column, src/NeRF.py:209)
     if (int r = ensure(c, c->b_orig, (size_t)N * 16)) return r;
     if (int r = ensure(c, c->b_dirs, (size_t)N * 16)) return r;
@@ -558,7 +594,8 @@ int nerf_render_image(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32
         if (u_f) duf = u_f + ray_begin * Sf;
     }
     const OutSizes sz = out_sizes(S);
-    for (long long off = 0; off < N; off += batch) {
+    size_t k = 0;
+    for (long long off = 0; off < N; off += batch, ++k) {
         const long long n = std::min<long long>(batch, N - off);
         nerf_outputs part = dev;
         for (int i = 0; i < 7; ++i) {
@@ -567,10 +604,30 @@ int nerf_render_image(nerf_ctx* c, const float* c2w, float fov, int32_t H, int32
         }
         if (int r = dev_render(c, (const float*)c->b_orig.p + off * 4, (const float*)c->b_dirs.p + off * 4, n, Sc, Sf,
                                duc ? duc + off * Sc : nullptr, (duf && fine) ? duf + off * Sf : nullptr, seed,
-                               ray_begin + off, part))
+                               ray_begin + off, part)) {
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
             return r;
+        }
+        if (mem == NERF_MEM_HOST)
+            if (int r = copy_back_batch(c, outs, &dev, off, n, S, k)) { (void)hipStreamSynchronize(c->copy_stream); return r; }
     }
-    if (mem == NERF_MEM_HOST) return copy_back_outputs(c, outs, &dev, N, S);
+    // the last copy waits for the last batch: an idle copy stream means the whole call is done
+    if (mem == NERF_MEM_HOST && c->copy_stream) HIP_OK(hipStreamSynchronize(c->copy_stream));
+    return 0;
+}
+
+// Page-locked host memory: destinations the device writes by DMA at link speed, beside running kernels.
+int nerf_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return fail("nerf_host_alloc of 0 bytes");
+    HIP_OK(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return 0;
+}
+
+int nerf_host_free(void* p) {
+    if (!p) return 0;
+    HIP_OK(hipHostFree(p));
     return 0;
 }
 

@@ -45,6 +45,8 @@ struct nerf_ctx {
     int num_cus = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;         // device-to-host copies of nerf_render_image(NERF_MEM_HOST), beside the kernels
+    std::vector<hipEvent_t> copy_ev;           // "batch k is done" events the copy stream waits on (ring)
     nerf::NetWeights net[2];
     // scratch arena (grow-only)
     nerf::DevBuf b_orig, b_dirs, b_zc, b_zf, b_raw, b_wc, b_u0, b_u1, b_in0, b_in1, b_in2;

