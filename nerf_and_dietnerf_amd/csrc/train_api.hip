@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "nerf_ctx.h"
@@ -105,6 +106,9 @@ int relayout_net(nerf_ctx* c, TNet& n) {
     if (n.fstream)
         launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->train->mixed, c->stream);
     if (n.bstream) launch_repack_bwd(n.blob, c->train->bidx[n.bdx ? 1 : 0], n.bstream, c->stream);
+    // the padded W / W^T / hi-lo planes feed the layer-wise GEMMs only; the fused forward + backward read the two
+    // re-packed streams above and nothing else (22 launches per step that nobody read)
+    if (c->train->training && c->train->frag) { HIP_OK(hipGetLastError()); return 0; }
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
@@ -284,8 +288,42 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
 }
 
 // ---- one pass: backward --------------------------------------------------------------------------
+// The 256-wide layers' weight gradients of a pass (fused backward: every D_l exists before the first of them starts) are
+// queued and leave as ONE GEMM launch + ONE reduction launch: two rounds of workgroups over the chip with ~56 row slabs per
+// layer instead of 256 (a quarter of the partial-sum bytes: 2.1 GB -> 0.45 GB per step), 2 kernel boundaries instead of 16.
+struct WgradQueue {
+    GemmAtbBatch gemm{};
+    ReduceBatch red{};
+    bool open = false;
+};
+
+void wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
+    q.open = false;
+    if (q.gemm.n == 0) return;
+    int units = 0;
+    for (int e = 0; e < q.gemm.n; ++e) units += (q.gemm.e[e].Kp + 255) / 256 * ((q.gemm.e[e].Nw + 255) / 256);
+    // one 512-thread workgroup per CU: two full rounds of the chip (every workgroup streams the same number of rows)
+    const int want_splits = std::max(8, 2 * c->num_cus / units);
+    long long rps = (Mp + want_splits - 1) / want_splits;
+    rps = (rps + 31) / 32 * 32;
+    const int splits = (int)((Mp + rps - 1) / rps);
+    size_t off = 0;
+    for (int e = 0; e < q.gemm.n; ++e) {
+        GemmAtb& g = q.gemm.e[e];
+        g.rows_per_split = (int)rps;
+        g.partial = (float*)t->partial.p + off;
+        q.red.e[e].partial = g.partial;
+        q.red.e[e].splits = splits;
+        off += (size_t)splits * (g.Kp + 1) * g.Nw;
+    }
+    if (t->mixed) launch_gemm_atb_f16_batch(q.gemm, c->stream, true);
+    else launch_gemm_atb_h_batch(q.gemm, c->stream, true);
+    launch_reduce_grad_batch(q.red, c->stream);
+    q.gemm.n = q.red.n = 0;
+}
+
 void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
-           int n_src_off, long long Mp, const unsigned* gmax = nullptr) {
+           int n_src_off, long long Mp, const unsigned* gmax = nullptr, WgradQueue* q = nullptr) {
     const TLayer& L = n.L[l];
     GemmAtb g{};
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
@@ -300,15 +338,21 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     rps = t->frag ? (rps + 31) / 32 * 32 : (rps + 15) / 16 * 16;     // fragment-major operands: whole 32-row blocks
     g.rows_per_split = (int)rps;
     g.gmax = gmax;
+    ReduceArgs r{};
+    r.Kp = L.Kp; r.Nw = Ncols;
+    r.grad_w = n.grad + L.w_off; r.grad_b = n.grad + L.b_off;
+    r.K_real = L.K_real; r.N_real = L.N_real; r.n_src_off = n_src_off; r.rowmap = L.rowmap;
+    r.accumulate = t->acc_grads ? 1 : 0;
+    if (q && q->open && wide && reduce_grad_is_wide(r) && q->gemm.n < kWgradBatchMax) {
+        q->gemm.e[q->gemm.n++] = g;               // slabs and partial regions are laid out by wgrad_flush
+        q->red.e[q->red.n++] = r;
+        return;
+    }
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
     else if (t->mixed) launch_gemm_atb_f16(g, c->stream, wide);
     else if (f16) launch_gemm_atb_h(g, c->stream, wide);
     else launch_gemm_atb(g, c->stream);
-    ReduceArgs r{};
-    r.partial = g.partial; r.Kp = L.Kp; r.Nw = Ncols; r.splits = (int)((Mp + rps - 1) / rps);
-    r.grad_w = n.grad + L.w_off; r.grad_b = n.grad + L.b_off;
-    r.K_real = L.K_real; r.N_real = L.N_real; r.n_src_off = n_src_off; r.rowmap = L.rowmap;
-    r.accumulate = t->acc_grads ? 1 : 0;
+    r.partial = g.partial; r.splits = (int)((Mp + rps - 1) / rps);
     launch_reduce_grad(r, c->stream);
 }
 
@@ -375,18 +419,21 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
         wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
         wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0));
-        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(1));
-        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(2));
-        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(3));
-        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(4));
-        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5));
-        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6));
-        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7));
+        WgradQueue wq;
+        wq.open = t->wgrad_wide;
+        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(1), &wq);
+        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(2), &wq);
+        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(3), &wq);
+        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(4), &wq);
+        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5), &wq);
+        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6), &wq);
+        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7), &wq);
         // (the xyz encoding's columns 256.. of C4: in the fragment-major buffer a column offset c is 32 c ELEMENTS --
         // half the byte offset under the fp16 policy)
         const size_t xyz_off = (size_t)32 * 256;
         const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
-        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8));
+        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8), &wq);
+        wgrad_flush(c, t, wq, Mp);
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
             launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream, true);
@@ -476,7 +523,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     r |= ensure(c, t->G9, Mmax * 128 * f);
     r |= ensure(c, t->Graw, Mmax * 4 * f);
     r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
-    r |= ensure(c, t->partial, (size_t)kTrainSplitsWide * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->partial, (size_t)2 * kTrainSplitsWide * (kLdC4 + 1) * 256 * f);   // also holds a pass's batched slabs
     r |= ensure(c, t->d_rgb, N * 3 * f);
     r |= ensure(c, t->d_wext, dc.M * f);
     r |= ensure(c, t->d_zf, (fine ? df.M : 1) * f);
@@ -579,7 +626,7 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     r |= ensure(c, t->G9, Mmax * 128 * f);
     r |= ensure(c, t->Graw, Mmax * 4 * f);
     r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
-    r |= ensure(c, t->partial, (size_t)kTrainSplitsWide * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->partial, (size_t)2 * kTrainSplitsWide * (kLdC4 + 1) * 256 * f);   // also holds a pass's batched slabs
     r |= ensure(c, t->d_wext, dc.M * f);
     r |= ensure(c, t->d_zf, (fine ? N * (long long)Sf : 1) * f);
     r |= ensure(c, t->z_new, (fine ? N * (long long)Sf : 1) * f);

@@ -53,13 +53,17 @@ struct GemmAtb {
     int a_f16;                          // head_wgrad: A holds fp16 elements (lda in halfs); gemm_atb_f16: both operands do
     int frag;                           // A and G (not the heads' 4-wide G) are fragment-major (frag_layout.h::frag_index); rows_per_split % 32 == 0
 };
+constexpr int kWgradBatchMax = 10;   // GEMMs per batched weight-gradient launch (the eight 256-wide layers of a pass fit)
+struct GemmAtbBatch { int n; int wg_end[kWgradBatchMax]; GemmAtb e[kWgradBatchMax]; };
 void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // same contract on the fp16 matrix cores: both operands split hi + lo (22 bits) on the fly while they are staged into LDS,
 // three MFMA passes, fp32 accumulation; G is pre-scaled by a power of two so that its largest entry sits at 2^14
 void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide = false);   // wide: 256 x 256 tile, 512 threads
+void launch_gemm_atb_h_batch(GemmAtbBatch& b, hipStream_t s, bool wide);      // all entries in ONE launch (fills wg_end)
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s);   // N = 4 (the heads): VALU kernel, same partial layout
 // mixed_float16 policy: A and G are fp16 rows (lda / ldg in halfs), one MFMA pass, no scaling (G carries the loss scale)
 void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide = false);
+void launch_gemm_atb_f16_batch(GemmAtbBatch& b, hipStream_t s, bool wide);
 
 // grad[blob layout] = sum over splits of partial (deterministic order)
 struct ReduceArgs {
@@ -70,6 +74,9 @@ struct ReduceArgs {
     int accumulate;                     // 1: add to the gradient blob instead of overwriting it
 };
 void launch_reduce_grad(const ReduceArgs& a, hipStream_t s);
+struct ReduceBatch { int n; ReduceArgs e[kWgradBatchMax]; };
+bool reduce_grad_is_wide(const ReduceArgs& a);                       // takes the 16-byte-load kernel (batchable)
+void launch_reduce_grad_batch(const ReduceBatch& b, hipStream_t s);  // one launch, grid row e = entry e
 
 // blob (Keras order) -> padded training matrices W [Kp x Np], WT [Np x Kp], bias [Np]
 struct RelayoutArgs {

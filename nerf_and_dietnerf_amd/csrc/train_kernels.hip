@@ -384,8 +384,20 @@ __device__ __forceinline__ void split_pack2(float v0, float v1, uint32_t& hi, ui
 }
 
 // W = tile width and height (128: four waves of 64 x 64; 256: eight waves of 128 x 64, A and G each read once per slab)
+// The weight-gradient kernels take a BATCH of GEMMs (GemmAtbBatch): the workgroups of entry e are blockIdx.x in
+// [wg_end[e-1], wg_end[e]) -- the trainer hands the eight 256-wide layers of a pass to ONE launch (a chip-filling grid with
+// a quarter of the row slabs per layer, hence a quarter of the partial-sum traffic, and one kernel boundary instead of eight).
+__device__ __forceinline__ int batch_entry(const GemmAtbBatch& b, int& lin) {
+    int e = 0;
+    while (e + 1 < b.n && lin >= b.wg_end[e]) ++e;
+    if (e > 0) lin -= b.wg_end[e - 1];
+    return e;
+}
+
 template <int W>
-__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_h_kernel(const GemmAtb g) {
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_h_kernel(const GemmAtbBatch bat) {
+    int lin = blockIdx.x;
+    const GemmAtb& g = bat.e[batch_entry(bat, lin)];
     constexpr int kPl = W * kHColStride;          // bytes per plane
     constexpr int WNW = W / 64;                   // waves along n (2 or 4); two along k
     constexpr int KTL = W / 64;                   // 32-row k tiles per wave (2 or 4); two n tiles per wave
@@ -395,7 +407,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int li = lane & 31, lh = lane >> 5;
     const int kt_n = (g.Kp + W - 1) / W, nt_n = (g.Nw + W - 1) / W, T = kt_n * nt_n;
     const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
+    if (lin >= T * n_splits) return;              // padding workgroups of a batch entry (its range is a multiple of 8)
+    const int grp = lin / (8 * T), rem = lin % (8 * T);
     int split = grp * 8 + rem % 8, tile = rem / 8;
     if (grp * 8 + 8 > n_splits) {
         const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
@@ -546,15 +559,31 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     }
 }
 
-void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
-    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    if (wide) {
-        const int tiles = ((g.Kp + 255) / 256) * ((g.Nw + 255) / 256);
-        hipLaunchKernelGGL(gemm_atb_h_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, s, g);
-    } else {
-        const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
-        hipLaunchKernelGGL(gemm_atb_h_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+// workgroup ranges of a batch: entry e gets tiles x splits workgroups, rounded up to a multiple of 8 so that every entry
+// starts on XCD 0 (the tile order inside an entry is XCD-aware)
+static int batch_ranges(GemmAtbBatch& b, int W) {
+    int end = 0;
+    for (int e = 0; e < b.n; ++e) {
+        const GemmAtb& g = b.e[e];
+        const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+        const int tiles = ((g.Kp + W - 1) / W) * ((g.Nw + W - 1) / W);
+        end += (tiles * splits + 7) / 8 * 8;
+        b.wg_end[e] = end;
     }
+    return end;
+}
+
+void launch_gemm_atb_h_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
+    if (b.n <= 0) return;
+    const int wgs = batch_ranges(b, wide ? 256 : 128);
+    if (wide) hipLaunchKernelGGL(gemm_atb_h_kernel<256>, dim3((unsigned)wgs), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL(gemm_atb_h_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, s, b);
+}
+
+void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
+    GemmAtbBatch b{};
+    b.n = 1; b.e[0] = g;
+    launch_gemm_atb_h_batch(b, s, wide);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -566,8 +595,10 @@ void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
 // gradient that left the fp16 range arrives as Inf and makes the partial sums non-finite: the loss-scale logic skips
 // that step (src/NeRF.py:159-163 under LossScaleOptimizer).
 // ------------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_f16_kernel(const GemmAtb g) {
+template <int W, bool FRAG>
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_f16_kernel(const GemmAtbBatch bat) {
+    int lin = blockIdx.x;
+    const GemmAtb& g = bat.e[batch_entry(bat, lin)];
     constexpr int kPl = W * kHColStride;
     constexpr int WNW = W / 64;
     constexpr int KTL = W / 64;
@@ -581,7 +612,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const int li = lane & 31, lh = lane >> 5;
     const int kt_n = (g.Kp + W - 1) / W, nt_n = (g.Nw + W - 1) / W, T = kt_n * nt_n;
     const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
-    const int lin = blockIdx.x, grp = lin / (8 * T), rem = lin % (8 * T);
+    if (lin >= T * n_splits) return;              // padding workgroups of a batch entry
+    const int grp = lin / (8 * T), rem = lin % (8 * T);
     int split = grp * 8 + rem % 8, tile = rem / 8;
     if (grp * 8 + 8 > n_splits) {
         const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
@@ -599,9 +631,10 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
     const int col = on ? (isG ? nb : kb) + 4 * cg : 0;
     // fragment-major operands (frag_layout.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive elements
-    const int rs = g.frag ? 4 : ld;                                   // elements between two of its rows
+    // -- with FRAG known at compile time they are fetched as two 16-byte loads instead of four 8-byte ones
+    const int rs = FRAG ? 4 : ld;                                     // elements between two of its rows
     const uint16_t* src = reinterpret_cast<const uint16_t*>(isG ? g.G : g.A) +
-                          (g.frag ? frag_index(ms + 4 * rg, col, ld) : (ms + 4 * rg) * ld + col);
+                          (FRAG ? frag_index(ms + 4 * rg, col, ld) : (ms + 4 * rg) * ld + col);
     const int wbase = (isG ? 1 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
 
     f32x16 acc[KTL][2];
@@ -633,11 +666,17 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     long long steps = 0;
     auto fetch1 = [&](uint2 (&r)[4], long long st) {
         const long long sc = st < steps ? st : steps - 1;
-        const uint16_t* q_ = src + (g.frag ? (size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64 : (size_t)sc * 16 * ld);
-        r[0] = *reinterpret_cast<const uint2*>(q_);
-        r[1] = *reinterpret_cast<const uint2*>(q_ + rs);
-        r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)rs);
-        r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)rs);
+        const uint16_t* q_ = src + (FRAG ? (size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64 : (size_t)sc * 16 * ld);
+        if constexpr (FRAG) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(q_), hi = *reinterpret_cast<const uint4*>(q_ + 8);
+            r[0] = make_uint2(lo.x, lo.y); r[1] = make_uint2(lo.z, lo.w);
+            r[2] = make_uint2(hi.x, hi.y); r[3] = make_uint2(hi.z, hi.w);
+        } else {
+            r[0] = *reinterpret_cast<const uint2*>(q_);
+            r[1] = *reinterpret_cast<const uint2*>(q_ + rs);
+            r[2] = *reinterpret_cast<const uint2*>(q_ + 2 * (size_t)rs);
+            r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)rs);
+        }
     };
     auto fetch = [&](uint2 (&r)[PB][4], long long pj) {
 #pragma unroll
@@ -731,15 +770,23 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     }
 }
 
-void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide) {
-    const int splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+void launch_gemm_atb_f16_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
+    if (b.n <= 0) return;
+    const int wgs = batch_ranges(b, wide ? 256 : 128);
+    const bool frag = b.e[0].frag != 0;           // one layout per trainer: all entries agree
     if (wide) {
-        const int tiles = ((g.Kp + 255) / 256) * ((g.Nw + 255) / 256);
-        hipLaunchKernelGGL(gemm_atb_f16_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, s, g);
+        if (frag) hipLaunchKernelGGL((gemm_atb_f16_kernel<256, true>), dim3((unsigned)wgs), dim3(512), 0, s, b);
+        else hipLaunchKernelGGL((gemm_atb_f16_kernel<256, false>), dim3((unsigned)wgs), dim3(512), 0, s, b);
     } else {
-        const int tiles = ((g.Kp + 127) / 128) * ((g.Nw + 127) / 128);
-        hipLaunchKernelGGL(gemm_atb_f16_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+        if (frag) hipLaunchKernelGGL((gemm_atb_f16_kernel<128, true>), dim3((unsigned)wgs), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gemm_atb_f16_kernel<128, false>), dim3((unsigned)wgs), dim3(256), 0, s, b);
     }
+}
+
+void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide) {
+    GemmAtbBatch b{};
+    b.n = 1; b.e[0] = g;
+    launch_gemm_atb_f16_batch(b, s, wide);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1154,10 +1201,12 @@ __global__ void reduce_grad_kernel(const ReduceArgs a) {
 // The wide layers (N_real, Nw and the source offset multiples of 4): a workgroup owns 64 float4 columns of the
 // [K + 1] x [N] gradient, its eight waves each add every eighth slab with 16-byte loads that cover whole 1 KiB rows of a
 // slab, and the eight sums meet in LDS in a fixed order.  (The 8-lane kernel read 32 bytes per row and instruction.)
-__global__ __launch_bounds__(512) void reduce_grad_vec_kernel(const ReduceArgs a) {
+__global__ __launch_bounds__(512) void reduce_grad_vec_kernel(const ReduceBatch bat) {
     __shared__ float4 sm[8][64];
+    const ReduceArgs& a = bat.e[blockIdx.y];      // one grid row per layer of the batch
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n4 = a.N_real / 4, total4 = (a.K_real + 1) * n4;
+    if ((int)blockIdx.x * 64 >= total4) return;   // the grid is as wide as the largest layer
     const int c4 = blockIdx.x * 64 + lane;
     const bool live = c4 < total4;
     const int cc = live ? c4 : 0;
@@ -1190,10 +1239,27 @@ __global__ __launch_bounds__(512) void reduce_grad_vec_kernel(const ReduceArgs a
     }
 }
 
+bool reduce_grad_is_wide(const ReduceArgs& a) {
+    return a.N_real % 4 == 0 && a.Nw % 4 == 0 && a.n_src_off % 4 == 0 && a.N_real >= 64;
+}
+
+// every entry must satisfy reduce_grad_is_wide
+void launch_reduce_grad_batch(const ReduceBatch& b, hipStream_t s) {
+    if (b.n <= 0) return;
+    int blocks = 0;
+    for (int e = 0; e < b.n; ++e) {
+        const int entries = (b.e[e].K_real + 1) * b.e[e].N_real;
+        blocks = blocks > (entries / 4 + 63) / 64 ? blocks : (entries / 4 + 63) / 64;
+    }
+    hipLaunchKernelGGL(reduce_grad_vec_kernel, dim3(blocks, b.n), dim3(512), 0, s, b);
+}
+
 void launch_reduce_grad(const ReduceArgs& a, hipStream_t s) {
     const int entries = (a.K_real + 1) * a.N_real;
-    if (a.N_real % 4 == 0 && a.Nw % 4 == 0 && a.n_src_off % 4 == 0 && a.N_real >= 64) {
-        hipLaunchKernelGGL(reduce_grad_vec_kernel, dim3((entries / 4 + 63) / 64), dim3(512), 0, s, a);
+    if (reduce_grad_is_wide(a)) {
+        ReduceBatch b{};
+        b.n = 1; b.e[0] = a;
+        launch_reduce_grad_batch(b, s);
     } else if (entries <= 4096) {
         hipLaunchKernelGGL(reduce_grad_kernel<64>, dim3((entries * 64 + 255) / 256), dim3(256), 0, s, a);
     } else {
