@@ -27,8 +27,10 @@ if ROOT not in sys.path:
 
 FLOPS_PER_ROW = 2 * 512152          # GEMM MACs per sample x 2
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak per dtype fed to MFMA
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
 H = W = 256
 SC, SF = 64, 128
+ALGO_BYTES_PER_FRAME = 256 * 256 * (32 + 12) + 2 * 514332 * 4      # rays + rgb + both networks' weights = 7.0 MB
 NEAR, FAR, FOV = 2.0 / 3.0, 5.0 / 3.0, 0.6911112
 
 
@@ -267,7 +269,9 @@ def main():
         return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_TFLOPS[dtype_key], "unit": "TFLOP/s",
                 "frac": a / PEAK_TFLOPS[dtype_key], "rows": int(rows), "flops_per_row": FLOPS_PER_ROW}
 
-    KERNEL = {"fp32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel", "f16": "mlp_f16_kernel"}
+    one_tile = os.environ.get("NERF_F16_TILES", "") == "1"
+    KERNEL = {"fp32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel",
+              "f16": "mlp_f16x3_kernel<single_pass>" if one_tile else "mlp_f16_2t_kernel"}
     DKEY = {"fp32": "f32", "f16x3": "f16x3", "f16": "f16"}
 
     def side_run(mdl, precision, k, h, w, sc, sf, pose, fov, batch=1 << 18, min_seconds=0.0):
@@ -388,6 +392,30 @@ def main():
         ls_mx = model.ctx.train_loss_scale()
         model.ctx.train_end()
         tf_tr = 3 * n_tr * (SC + SF) * FLOPS_PER_ROW / e_tr / 1e12
+        tf_mx = 3 * n_tr * (SC + SF) * FLOPS_PER_ROW / e_mx / 1e12
+        # HBM bytes of one step: rocprofv3 PMC passes collected OFFLINE over tools/train_bench.py (same batch), summed over
+        # the step's kernels by tools/pmc_summary_r3.py into profiles/pmc_traffic.json
+        tr_bytes = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                tr_bytes = json.load(f)
+        except Exception:
+            pass
+        # what a step must move at the least with this three-kernel structure (stash forward, fused data-gradient chain,
+        # weight-gradient GEMMs): every 256-wide activation and pre-activation gradient is written once and read once
+        rows_tr = n_tr * (SC + SF)
+        elems_per_row = 7 * 256 + 320 + 288 + 128 + 8 * 256 + 128      # stash (incl. the two concat buffers) + D buffers
+
+        def hbm_view(ms, key, elem_bytes):
+            by = tr_bytes.get(key)
+            algo = rows_tr * elems_per_row * elem_bytes * 2.0
+            return {"bound": "hbm", "achieved": (by / (ms * 1e-3) / 1e9) if by else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": (by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if by else None, "traffic": by,
+                    "traffic_source": "offline rocprofv3 PMC, summed over the kernels of one step (profiles/pmc_traffic.json)",
+                    "structural_bytes": algo, "traffic_vs_structural": (by / algo) if by else None,
+                    "note": "the step is HBM-bound: activations and pre-activation gradients are written once (stash "
+                            "forward, backward chain) and read once (weight-gradient GEMMs); structural_bytes counts "
+                            "exactly that. SURVEY 8(d)-style algorithmic bytes (rays + weights + moments) are ~20 MB."}
         train = {"metric": "train_step (NeRF.train_step: coarse+fine forward, backward incl. sampler, Adam)",
                  "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                  "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
@@ -399,15 +427,44 @@ def main():
                                           "note": "the reference's production policy (src/ExecutionRun.py:220-221, "
                                                   "src/NeRF.py:159-163): single-pass fp16 forward, data and weight "
                                                   "gradients on fp16 activation / gradient buffers, fp32 accumulation "
-                                                  "and master weights, dynamic loss scaling"},
-                 "roofline": {"bound": "mfma",
-                              "kernel": "whole step: mlp_f16x3_stash_kernel (fused forward) + mlp_bwd_f16x3[_dx]_kernel "
-                                        "(fused data-gradient chain) + gemm_atb_h (weight gradients), all 3-pass "
-                                        "split-fp16 MFMA with fp32 accumulation",
-                              "achieved": tf_tr, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
-                              "frac": tf_tr / PEAK_TFLOPS["f16x3"], "frac_vs_fp32_matrix_peak": tf_tr / PEAK_TFLOPS["f32"],
-                              "mfma_passes_per_product": 3,
-                              "flops": "3 x forward GEMM flops (forward, data gradient, weight gradient)"}}
+                                                  "and master weights, dynamic loss scaling",
+                                          "roofline": dict(hbm_view(e_mx, "train_step_mixed", 2),
+                                                           mfma_view={"achieved": tf_mx, "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
+                                                                      "frac": tf_mx / PEAK_TFLOPS["f16"], "mfma_passes_per_product": 1,
+                                                                      "flops": "3 x forward GEMM flops"})},
+                 "roofline": dict(hbm_view(e_tr, "train_step_f32", 4),
+                                  kernel="whole step: mlp_f16x3_stash_kernel (fused forward) + mlp_bwd_f16x3[_dx]_kernel "
+                                         "(fused data-gradient chain) + gemm_atb_h (weight gradients, batched per pass), "
+                                         "all 3-pass split-fp16 MFMA with fp32 accumulation",
+                                  mfma_view={"achieved": tf_tr, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
+                                             "frac": tf_tr / PEAK_TFLOPS["f16x3"], "frac_vs_fp32_matrix_peak": tf_tr / PEAK_TFLOPS["f32"],
+                                             "mfma_passes_per_product": 3,
+                                             "flops": "3 x forward GEMM flops (forward, data gradient, weight gradient)"})}
+
+    # the drop-in boundary itself: the host-memory entry point (numpy in, numpy out), one synchronous call per frame --
+    # page-locked outputs, copies on a second stream; next to the same call with device-resident outputs (N=1 only)
+    host_boundary = None
+    if world == 1 and args.rehearse_world <= 1 and not args.quick:
+        def frames_per_s(f, k):
+            f(100), f(101)
+            t_ = time.perf_counter()
+            for i in range(k):
+                f(i)
+            return k / (time.perf_counter() - t_)
+
+        def f_dev(i):
+            model.render_image(c2w, FOV, H, W, seed=i, rgb_only=True, device_out=True)
+            sync()
+        model.ctx.set_precision(args.precision)
+        r_dev = frames_per_s(f_dev, 8) * total
+        r_rgb = frames_per_s(lambda i: model.render_image(c2w, FOV, H, W, seed=i, rgb_only=True), 8) * total
+        r_six = frames_per_s(lambda i: model.render_image(c2w, FOV, H, W, seed=i), 5) * total
+        host_boundary = {"unit": "rays/s", "calls": "synchronous, one per 256x256 frame (the steady-state headline enqueues frames back to back)",
+                         "device_resident_rgb": r_dev, "host_rgb_only": r_rgb, "host_six_outputs": r_six,
+                         "host_rgb_only_vs_device": r_rgb / r_dev, "host_six_outputs_vs_device": r_six / r_dev,
+                         "bytes_to_host_per_frame": {"rgb_only": total * 12, "six_outputs": total * (12 + (SC + SF) * 28)},
+                         "note": "nerf_render_image(NERF_MEM_HOST) into page-locked buffers (nerf_host_alloc): outputs leave on a "
+                                 "copy stream behind per-batch events while the next batch computes; never the headline value"}
 
     if rank == 0:
         value = total * args.steps / elapsed
@@ -439,11 +496,15 @@ def main():
             "config": {"workload": "256x256 synthetic scene, 64 coarse + 128 fine (BASELINE configs[1]); contractions in " + {"f32": "exact fp32 MFMA", "f16x3": "3-pass split-fp16 MFMA, fp32 accumulate", "f16": "1-pass fp16 MFMA, fp32 accumulate"}[dtype],
                        "rays_per_step": total, "mlp_rows_per_ray": SC + SC + SF,
                        "parallelism": f"ray-sharded x{world}, one all-gather of RGB per frame"},
-            "roofline": {"bound": "mfma", "kernel": {"f32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel", "f16": "mlp_f16_kernel"}[dtype] + " (fused PE + 11-layer MLP)",
+            "roofline": {"bound": "mfma", "kernel": {"f32": "mlp_fp32_kernel", "f16x3": "mlp_f16x3_kernel", "f16": "mlp_f16x3_kernel<single_pass>" if os.environ.get("NERF_F16_TILES", "") == "1" else "mlp_f16_2t_kernel"}[dtype] + " (fused PE + 11-layer MLP)",
                          "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[dtype], "frac_vs_fp32_matrix_peak": ach / PEAK_TFLOPS["f32"],
                          "mfma_passes_per_product": 3 if dtype == "f16x3" else 1, "traffic": traffic,
                          "traffic_source": "offline rocprofv3 PMC (profiles/pmc_traffic.json), bytes per average launch",
+                         # 32 B/ray in (generated on device: 0 from the host) + 12 B/ray rgb out + one
+                         # read of both networks' weights per frame; two launches per frame
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME / 2,
+                         "traffic_vs_algorithmic": (traffic / (ALGO_BYTES_PER_FRAME / 2)) if traffic else None,
                          "launches": int(n_launch), "avg_launch_ms": mlp_ms / max(n_launch, 1),
                          "flops_per_row": FLOPS_PER_ROW, "rows": int(n_rows)},
         }
@@ -460,6 +521,8 @@ def main():
             out["per_rank"] = per_rank
         if train is not None:
             out["training"] = train
+        if host_boundary is not None:
+            out["host_boundary"] = host_boundary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
         print(json.dumps(out), flush=True)

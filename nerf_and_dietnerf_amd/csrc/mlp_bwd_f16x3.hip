@@ -89,11 +89,18 @@ __device__ __forceinline__ float pow2_inverse(float r) { return __uint_as_float(
 __device__ __forceinline__ float max_with_other_half(float v) {   // max over the two lanes (j, 0) and (j, 1) of a sample
     return fmaxf(v, __shfl_xor(v, 32));
 }
-// 1.0 or alpha by bit `BIT` of w: sign-extended bit -> all-ones / zero -> bitfield insert (3 plain VALU ops with the mul)
+// `neg` or `pos` by bit BIT of the LeakyReLU' record w (set = negative activation): the bit sign-extended to all-ones /
+// zero, then a bitfield insert -- two plain VALU ops, in asm because hipcc turns the C form into and + compare + select
 template <int BIT>
-__device__ __forceinline__ float mask_factor(uint32_t w, float alpha) {
-    const int m = ((int)(w << (31 - BIT))) >> 31;
-    return __uint_as_float(((uint32_t)m & 0x3F800000u) | (~(uint32_t)m & __float_as_uint(alpha)));
+__device__ __forceinline__ int mask_ones(uint32_t w) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(BIT));
+    return m;
+}
+__device__ __forceinline__ float mask_select(int m, float neg, float pos) {
+    float f;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(m), "v"(neg), "v"(pos));
+    return f;
 }
 
 // One transposed layer.  Tiles 0..NX-1 produce rows of the encoding gradient (true scale, no mask, not re-packed), the
@@ -108,6 +115,13 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                                          float* d_prev, float* d_cur, float* dx_cur, const frag4& mk_prev,
                                          const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[4], frag4 (&xh)[16],
                                          frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14]) {
+#ifndef NERF_BWD_EXTRA_FAST
+#define NERF_BWD_EXTRA_FAST 0
+#endif
+#ifndef NERF_BWD_EXTRA_3P
+#define NERF_BWD_EXTRA_3P 0
+#endif
+    constexpr int kBwdExtra = FAST ? NERF_BWD_EXTRA_FAST : NERF_BWD_EXTRA_3P;
     constexpr int NH = KIND == BW_XYZ ? 0 : 8;
     constexpr int NU = NX + NH;
     constexpr int NSTEP = KIND == BW_HEAD ? kBStepsHead : 16;
@@ -140,12 +154,21 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         *reinterpret_cast<f32x4*>(base + (decltype(fragc)::value ? 32 : 1) * (c0 + 8 * (r >> 2))) = o;
     };
     // register r of hidden tile ht: mask, write the true value, scale + split + pack into the next operand
-    auto hidden_reg = [&](auto htc, auto rc, float acc_v, const frag4& mk, float inv_s, float rho_s, float* dst,
-                          auto to_x) {
+    // alpha folded into the four scales once per body (pinned: left to itself hipcc re-multiplies per value rather than
+    // hold the registers)
+    auto pinned = [](float v) { asm volatile("" : "+v"(v)); return v; };
+    const float ainv_prev = pinned(alpha * L.inv_prev), arho_prev = pinned(alpha * L.rho_prev);
+    const float ainv_cur = pinned(alpha * L.inv_sig);
+    float arho_cur = pinned(alpha * L.rho);           // renewed with L.rho (PEND bodies fix it at k-step 8 of tile 0)
+    auto hidden_reg = [&](auto htc, auto rc, float acc_v, const frag4& mk, float inv_s, float rho_s, float ainv_s,
+                          float arho_s, float* dst, auto to_x) {
         constexpr int ht = decltype(htc)::value;
         constexpr int r = decltype(rc)::value;
-        const float v = acc_v * mask_factor<(ht & 1) * 16 + r>(mk[ht >> 1], alpha);
-        const float t = v * inv_s;
+        // t = acc * LeakyReLU' / scale-in (the true value), pk = acc * LeakyReLU' * scale-out (the next operand): LeakyReLU'
+        // is folded into the two power-of-two scales (exact), one selected factor each -- bfe + 2 bfi + 2 mul where
+        // and + compare + select + three multiplications were 6 VALU ops per value
+        const int neg = mask_ones<mask_bit(ht, r)>(mk[ht >> 1]);
+        const float t = acc_v * mask_select(neg, ainv_s, inv_s);
         if constexpr (FAST) {
             // mixed_float16 policy: D is stored in fp16 (dst points at fp16 rows).  The values carry the loss scale, as
             // the policy's activation gradients do: an overflow becomes Inf here, NaN in the weight gradient, and the
@@ -160,7 +183,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             else if constexpr ((r & 3) == 2) q2 = t;
             else store4(dst, 32 * ht, r, t, std::true_type{});
         }
-        const float pk = v * rho_s;
+        const float pk = acc_v * mask_select(neg, arho_s, rho_s);
         L.mrun = fmaxf(L.mrun, fabsf(pk));
         if constexpr ((r & 1) == 0) pc = pk;
         else {
@@ -206,7 +229,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                 if constexpr (qc == 0 && Q > 0) p.ck += 1;
                 if constexpr (qc == kBCQ / 2) {
                     constexpr int room = (NQ - 1 - Q) / 2;
-                    pipe_sync_c<kBCQ, kBRing, (room + 1 < kBCQ / 4 ? room + 1 : kBCQ / 4)>(p);
+                    pipe_sync_c<kBCQ, kBRing, (room + 1 < kBCQ / 4 ? room + 1 : kBCQ / 4), kBwdExtra>(p);
                 }
                 if constexpr (qc > kBCQ / 2 && (qc - kBCQ / 2) % 2 == 0) {
                     constexpr int Qs = Q - (qc - kBCQ / 2);
@@ -247,15 +270,16 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             if constexpr (u == 0 && PEND) {
                 if constexpr (n < 8) {           // previous body's hidden tile 7, a register pair per k-step
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                               mk_prev, L.inv_prev, L.rho_prev, d_prev, std::true_type{});
+                               mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{});
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n + 1>{},
-                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, d_prev, std::true_type{});
+                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{});
                 }
                 if constexpr (n == 8) {
                     // this body's operand is complete: its peak fixes the scale of this body's outputs, and (in true
                     // scale) is max|D| of the buffer the previous body wrote
                     const float m_in = max_with_other_half(L.mrun);
                     L.rho = pow2_to_peak(m_in);
+                    arho_cur = pinned(alpha * L.rho);
                     L.mrun = 0.f;
                     atomicMax(lds_gmax() + gslot_prev, __float_as_uint(m_in * L.inv_sig));
                     if (copy_tail) { xh[12] = nh[12]; xl[12] = nl[12]; }
@@ -270,12 +294,12 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                     constexpr int ht = pt - NX;
                     if constexpr (NSTEP >= 16) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, n>{}, prv[n], mk_cur,
-                                   L.inv_sig, L.rho, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                                   L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
                     } else if constexpr (n < 8) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                                   mk_cur, L.inv_sig, L.rho, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                                   mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n + 1>{},
-                                   prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, d_cur,
+                                   prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur,
                                    std::integral_constant<bool, KIND == BW_HEAD>{});
                     }
                 }
@@ -292,7 +316,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             xyz_reg(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
         });
     }
-    if constexpr (NQ % kBCQ != 0 && NQ % kBCQ <= kBCQ / 2) pipe_sync_c<kBCQ, kBRing, 1>(p);
+    if constexpr (NQ % kBCQ != 0 && NQ % kBCQ <= kBCQ / 2) pipe_sync_c<kBCQ, kBRing, 1, kBwdExtra>(p);
     p.ck += 1;
 }
 
@@ -362,9 +386,9 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int bit = (t & 1) * 16 + 8 * s + 4 * g + e;
+                    const int bit = mask_bit(t, 8 * s + 4 * g + e);
                     float v = w0[e] * graw[0] + w1[e] * graw[1] + w2[e] * graw[2];
-                    v = ((mq[0][t >> 1] >> bit) & 1u) ? v : alpha * v;
+                    v = ((mq[0][t >> 1] >> bit) & 1u) ? alpha * v : v;
                     o[e] = v;
                     g9[n * 8 + g * 4 + e] = v;
                     mt = fmaxf(mt, fabsf(v));
@@ -455,8 +479,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int bit = 16 + r + e;
-                    const float v = last[r + e] * (((mk_cur[3] >> bit) & 1u) ? 1.0f : alpha) * L.inv_prev;
+                    const int bit = mask_bit(7, r + e);
+                    const float v = last[r + e] * (((mk_cur[3] >> bit) & 1u) ? alpha : 1.0f) * L.inv_prev;
                     o[e] = v;
                     tmax = fmaxf(tmax, fabsf(v));
                 }

@@ -150,13 +150,16 @@ __device__ __forceinline__ void pipe_piece_c(Pipe& p) {
 }
 
 // pipe_sync_t with a compile-time first_unplaced (so its pieces can use the offset form)
-template <int CQ, int RING, int FIRST_UNPLACED>
+// EXTRA: vector-memory operations (stores of the training kernels) that the caller GUARANTEES to have issued since the
+// previous sync: gfx9 counts loads and stores on one in-order vmcnt, so they may stay outstanding beside the NPIECE
+// DMA pieces of the chunk after next without the wait becoming weaker for the chunk it is about.
+template <int CQ, int RING, int FIRST_UNPLACED, int EXTRA = 0>
 __device__ __forceinline__ void pipe_sync_c(Pipe& p) {
     constexpr int NPIECE = CQ / 4;
 #if defined(NERF_DIAG) && NERF_DIAG == 2
     asm volatile("" ::: "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(NPIECE * (RING - 3)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(NPIECE * (RING - 3) + EXTRA) : "memory");
 #if !(defined(NERF_DIAG) && NERF_DIAG == 1)
     __builtin_amdgcn_s_barrier();
 #endif

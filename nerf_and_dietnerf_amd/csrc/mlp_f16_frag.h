@@ -94,6 +94,17 @@ static_assert(kXConstFloats <= kConstFloats, "xyz-only constants must fit the sh
 enum { BODY_HIDSIG = 4, BODY_LAST0 = 5 };
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");
 
+// LeakyReLU' record shared by the stash forward (writer) and the fused backward (reader): per lane and layer four 32-bit
+// words, word ut >> 1 for output tiles ut, ut + 1; the epilogue handles a tile's 16 accumulator registers as 8 pairs in
+// order and pushes each pair's two fp16 SIGN bits (bits 15 and 31 of the packed pair) into its word from the top, so
+// after a word's 16 pushes pair k (k = 8 (ut & 1) + r / 2) sits at bits k (even register) and 16 + k (odd register).
+// A set bit = negative activation = LeakyReLU' is alpha.  (An activation of exactly +0 counts as positive; the reference's
+// LeakyReLU gradient takes alpha there -- a measure-zero difference that only an all-zero weight row can produce.)
+__device__ __forceinline__ uint32_t mask_push(uint32_t word, uint32_t packed_pair) {
+    return (packed_pair & 0x80008000u) | (word >> 1);
+}
+__host__ __device__ constexpr int mask_bit(int ut, int r) { return 8 * (ut & 1) + (r >> 1) + 16 * (r & 1); }
+
 // activation fragment order shared by forward and backward: element e of lane half h of k-step n (n = 2t + s) is
 // feature 32t + 16s + 8(e>>2) + 4h + (e&3) -- the accumulator-as-operand order of the 32x32 C/D layout
 __host__ __device__ inline int frag_feature(int n, int e, int h) {

@@ -38,9 +38,10 @@ __device__ unsigned long long g_stamps_h[16];
 // FAST + STASH (the mixed_float16 policy's forward) writes the stash in fp16 -- the very dwords it packs as the next
 // layer's operand, four consecutive features per 8-byte store -- and st_prev / st_cur then point at fp16 rows.
 // It also records the LeakyReLU' masks the fused backward (mlp_bwd_f16x3.hip) multiplies by: one bit per activation
-// (1 = positive), bit 16 ut + r of the lane's 128-bit word mk_cur = accumulator register r of output tile ut, i.e.
-// exactly the layout in which the backward's accumulators hold the gradient of that activation; one 16-byte store
-// per lane and layer (32 B per sample row instead of re-reading the 1 KB stash row for its signs).
+// (its SIGN bit: 1 = negative), bit mask_bit(ut, r) (mlp_f16_frag.h) of word ut >> 1 of the lane's 128-bit record =
+// accumulator register r of output tile ut, i.e. indexed exactly as the backward's accumulators hold the gradient of
+// that activation; one 16-byte store per lane and layer (32 B per sample row instead of re-reading the 1 KB stash row
+// for its signs).
 // ROT rotates the four accumulators: tile u works in accs[(u + ROT) & 3] and a PENDING tile is looked for in
 // accs[(ROT + 3) & 3]; every body but BODY_LAST0 (which follows the 9-tile BODY_HIDSIG) uses ROT = 0.
 template <int BODY, bool PENDING, bool FAST, bool STASH = false, int ROT = 0>
@@ -70,6 +71,13 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
 #define NERF_KPF_FAST 8
 #endif
     constexpr int kPf = FAST ? NERF_KPF_FAST : NERF_KPF;   // single-pass: a quad is consumed every 32 cycles, look further ahead
+#ifndef NERF_STASH_EXTRA_FAST
+#define NERF_STASH_EXTRA_FAST 0
+#endif
+#ifndef NERF_STASH_EXTRA_3P
+#define NERF_STASH_EXTRA_3P 0
+#endif
+    constexpr int kStashExtra = STASH ? (FAST ? NERF_STASH_EXTRA_FAST : NERF_STASH_EXTRA_3P) : 0;
     f32x4 pf[kPf];
     const int ck0 = p.ck;   // chunk of quad 0 of this body; quad Q lives in chunk ck0 + Q/16
     uint32_t rdbase[2];     // LDS address of the ring slot of an even / odd chunk (refreshed as chunks retire)
@@ -126,26 +134,26 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         constexpr int n = 2 * ut + (r >> 3), e = r & 7;
-        if constexpr (STASH) {
-            if constexpr (FAST) stash4h(utc, rc, pack_h2(y0, y1), decltype(pend_sel)::value ? st_prev : st_cur);
-            else stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
-            constexpr int sh = (ut & 1) * 16 + r;
-            const uint32_t bits = (y0 > 0.f ? (1u << sh) : 0u) | (y1 > 0.f ? (2u << sh) : 0u);
-            if constexpr (decltype(pend_sel)::value) mk_prev[ut >> 1] |= bits;
-            else mk_cur[ut >> 1] |= bits;
-        }
+        uint32_t ph, pl = 0u;
         if constexpr (FAST) {
-            const uint32_t ph = pack_h2(y0, y1);                          // round to fp16, no lo part
-            if constexpr (decltype(dest_sel)::value) xh[n][e >> 1] = ph;
-            else nh[n][e >> 1] = ph;
+            ph = pack_h2(y0, y1);                                         // round to fp16, no lo part
         } else {
             float h0, l0, h1, l1;
             split_trunc(y0, h0, l0);
             split_trunc(y1, h1, l1);
-            const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);   // whole-register writes
-            if constexpr (decltype(dest_sel)::value) { xh[n][e >> 1] = ph; xl[n][e >> 1] = pl; }
-            else { nh[n][e >> 1] = ph; nl[n][e >> 1] = pl; }
+            ph = pack_h2(h0, h1); pl = pack_h2(l0, l1);                   // whole-register writes
         }
+        if constexpr (STASH) {
+            if constexpr (FAST) stash4h(utc, rc, ph, decltype(pend_sel)::value ? st_prev : st_cur);
+            else stash4(utc, rc, y0, y1, decltype(pend_sel)::value ? st_prev : st_cur);
+            // LeakyReLU' record: the two SIGN bits of the packed pair, shifted in (mask_push, mlp_f16_frag.h) -- two plain
+            // VALU ops per pair (two compares, two selects and an or before: the mask alone was a third of this
+            // kernel's VALU work beside the single-pass MFMAs)
+            if constexpr (decltype(pend_sel)::value) mk_prev[ut >> 1] = mask_push(mk_prev[ut >> 1], ph);
+            else mk_cur[ut >> 1] = mask_push(mk_cur[ut >> 1], ph);
+        }
+        if constexpr (decltype(dest_sel)::value) { xh[n][e >> 1] = ph; if constexpr (!FAST) xl[n][e >> 1] = pl; }
+        else { nh[n][e >> 1] = ph; if constexpr (!FAST) nl[n][e >> 1] = pl; }
     };
 
     float ycarry = 0.f;
@@ -169,7 +177,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 if constexpr (qc == kHCQ / 2) {
                     // pieces 1.. go out at quads +2, +4, ...; those that would fall past the body's end go now
                     constexpr int room = (NQ - 1 - Q) / 2;                 // pieces that still find a quad
-                    pipe_sync_c<kHCQ, kHRing, (room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4)>(p);
+                    pipe_sync_c<kHCQ, kHRing, (room + 1 < kHCQ / 4 ? room + 1 : kHCQ / 4), kStashExtra>(p);
                 }
                 if constexpr (qc > kHCQ / 2 && (qc - kHCQ / 2) % 2 == 0) {
                     // was this chunk's sync a tail case (pieces issued out of order)?  then re-establish M0
@@ -227,9 +235,12 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                     xc[et * 16 + n] = y;
                     if constexpr (STASH) {      // layer 8's outputs (128 features) go to the stash in fours as well
                         if constexpr ((n & 1) == 0) ycarry = y;
-                        else if constexpr (FAST) stash4h(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, pack_h2(ycarry, y), st_cur);
-                        else stash4(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, st_cur);
-                        mk_cur[et >> 1] |= y > 0.f ? (1u << ((et & 1) * 16 + n)) : 0u;
+                        else {
+                            const uint32_t pp = pack_h2(ycarry, y);
+                            if constexpr (FAST) stash4h(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, pp, st_cur);
+                            else stash4(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, st_cur);
+                            mk_cur[et >> 1] = mask_push(mk_cur[et >> 1], pp);
+                        }
                     }
                 }
                 else if constexpr ((n & 1) == 0) ycarry = y;
@@ -275,7 +286,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         sigma_raw = accs[(NU - 1) & 3][0];
         if constexpr (STASH) { if (mk_cur_ptr) *mk_cur_ptr = mk_cur; }   // layer 8 (128 features): all four tiles are finished
     }
-    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1>(p);
+    if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1, kStashExtra>(p);
     p.ck += 1;
 }
 
