@@ -84,14 +84,15 @@ def _image_names(path: str) -> List[str]:
 
 
 def load_llff_data(path_to_images: str):
-    """-> images (n,h,w,3) float32 in [0,1], poses_hwf (n,3,5) = [R | t | (h,w,focal)], bounds (2,n), the mean camera
+    """-> images (n,h,w,3) float32 in [0,1], poses_hwf (n,3,5) = [R | t | (h,w,focal)], bounds (n,2) = (near, far) per view
+    -- the shape the reference returns (src/UtilsFiles.py:113-114: transpose, then moveaxis(-1, 0)) --, the mean camera
     before recentring, scale.  poses_bounds.npy rows are 15 pose numbers (a 3x5 matrix whose rotation columns are
     (down, right, backwards)) followed by the near / far depth of the view."""
     table = np.load(os.path.join(path_to_images, POSES_BOUNDS_NPY), allow_pickle=False)
     llff = table[:, :15].reshape(-1, 3, 5)
     # LLFF stores the rotation columns as (down, right, back); the renderer wants (right, up, back)
     poses_hwf = np.concatenate([llff[:, :, 1:2], -llff[:, :, 0:1], llff[:, :, 2:]], axis=2)
-    bounds = np.ascontiguousarray(table[:, 15:].T)
+    bounds = table[:, 15:].copy()
     poses_hwf, mean_c2w = recenter_poses(poses_hwf)
     poses_hwf, bounds, scale = spherify_poses(poses_hwf, bounds)
     names = _image_names(path_to_images)

@@ -81,14 +81,97 @@ def _mlp(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float):
     return torch.cat([rgb, sigma], -1)
 
 
-def _render_rays(p, o, d, z, n_xyz, n_dir, n_angles, alpha):
-    """src/UtilsNeuralRadianceField.py:181-211 + ray_marching :88-115 -> (rgb (N,3), weights (N,S))."""
+# ---- emulation of the library's mixed_float16 training arithmetic (csrc/mlp_f16x3.hip FAST + STASH, mlp_bwd_f16x3.hip
+# FAST, train_kernels.hip::gemm_atb_f16) inside autograd: the numerics CLASS of the reference's production policy
+# (src/ExecutionRun.py:220-221), restated where the kernels round -- not TensorFlow's own op order (parity unpinned there).
+def _r16(x: torch.Tensor) -> torch.Tensor:
+    """Round to fp16 (RNE, subnormals and overflow as the hardware conversion) and come back."""
+    return x.to(torch.float32).to(torch.float16).to(x.dtype)
+
+
+def _ste16(x: torch.Tensor) -> torch.Tensor:
+    """fp16-rounded value in the forward pass, identity in the backward pass (the kernels differentiate through the
+    rounding the same way: the stashed fp16 activation stands for the activation)."""
+    return x + (_r16(x) - x).detach()
+
+
+def _r16_rows(g: torch.Tensor) -> torch.Tensor:
+    """The backward chain's operand packing: every sample row is scaled by its own power of two so that its largest entry
+    lies in (2^5, 2^6], rounded to fp16 and scaled back (mlp_bwd_f16x3.hip::pow2_to_peak)."""
+    m = g.detach().abs().amax(dim=-1, keepdim=True)
+    e = torch.where(m > 0, torch.ceil(torch.log2(torch.where(m > 0, m, torch.ones_like(m)))), torch.zeros_like(m))
+    s = torch.pow(torch.full_like(m, 2.0), 6.0 - e)                   # m * s in (2^5, 2^6]
+    return _r16(g * s) / s
+
+
+class _Dense16(torch.autograd.Function):
+    """y = x_q @ W_q + b with fp16 operands and wide accumulation, and the backward the kernels run:
+         D (the incoming pre-activation gradient) is STORED as fp16 carrying the loss scale -> weight / bias gradient
+         from the stashed fp16 input and that fp16 D (gemm_atb_f16: fp32 accumulation);
+         the data gradient multiplies the row-scaled fp16 packing of D with the fp16 weights.
+    store16 = False: the heads, whose weight gradients read the fp32 gradient of the raw outputs (head_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x_q, w, b, loss_scale, store16):
+        w_q = _r16(w)
+        ctx.save_for_backward(x_q, w_q)
+        ctx.ls, ctx.store16 = loss_scale, store16
+        return x_q @ w_q + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x_q, w_q = ctx.saved_tensors
+        g_st = _r16(g * ctx.ls) / ctx.ls if ctx.store16 else g
+        return _r16_rows(g) @ w_q.t(), x_q.t() @ g_st, g_st.sum(0), None, None
+
+
+class _RgbHead16(torch.autograd.Function):
+    """The 128 -> 3 head on the VALU: fp32 weights and the UNROUNDED last hidden layer in the forward pass and in the data
+    gradient; its weight gradient reads the stashed fp16 copy of that layer (head_wgrad_frag_kernel<true>)."""
+
+    @staticmethod
+    def forward(ctx, y9, w, b):
+        ctx.save_for_backward(y9, w)
+        return y9 @ w + b
+
+    @staticmethod
+    def backward(ctx, g):
+        y9, w = ctx.saved_tensors
+        return g @ w.t(), _r16(y9).t() @ g, g.sum(0)
+
+
+def _mlp16(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float, loss_scale: float):
+    """_mlp under the library's mixed_float16 arithmetic (view-direction network)."""
+    lrelu = lambda t: torch.nn.functional.leaky_relu(t, alpha)
+    dense = lambda x, i, st=True: _Dense16.apply(x, p[2 * i], p[2 * i + 1], loss_scale, st)
+    xq, dq = _ste16(xyz_enc), _ste16(dir_enc)
+    h = _ste16(lrelu(dense(xq, 0)))
+    for i in (1, 2, 3):
+        h = _ste16(lrelu(dense(h, i)))
+    h = _ste16(lrelu(dense(torch.cat([xq, h], -1), 4)))
+    for i in (5, 6, 7):
+        h = _ste16(lrelu(dense(h, i)))
+    hd = torch.cat([h, dq], -1)
+    y9 = lrelu(dense(hd, 8))                                          # stays fp32 for the VALU head
+    rgb = _RgbHead16.apply(y9, p[18], p[19])
+    sigma = dense(hd, 10, False)
+    return torch.cat([rgb, sigma], -1)
+
+
+def _render_rays(p, o, d, z, n_xyz, n_dir, n_angles, alpha, fp16_loss_scale=None):
+    """src/UtilsNeuralRadianceField.py:181-211 + ray_marching :88-115 -> (rgb (N,3), weights (N,S)).
+    fp16_loss_scale: run the network under the library's mixed_float16 arithmetic (see _mlp16) with this loss scale."""
     n, s = z.shape
     pts = (o[:, None, :3] + d[:, None, :3] * z[..., None]).reshape(-1, 3)
     comps = [0, 1, 2] if n_angles == 2 else [0, 2]                   # src/UtilsCV.py:124-143
     view = d[:, comps][:, None, :].expand(n, s, len(comps)).reshape(-1, len(comps))
     dir_enc = None if n_angles == 0 else _pe(view, n_dir, False)     # UtilsNeuralRadianceField.py:205
-    raw = _mlp(p, _pe(pts, n_xyz, True), dir_enc, alpha).reshape(n, s, 4)
+    if fp16_loss_scale is not None:
+        if n_angles != 2:
+            raise NotImplementedError("the fp16 emulation restates the view-direction network")
+        raw = _mlp16(p, _pe(pts, n_xyz, True), dir_enc, alpha, float(fp16_loss_scale)).reshape(n, s, 4)
+    else:
+        raw = _mlp(p, _pe(pts, n_xyz, True), dir_enc, alpha).reshape(n, s, 4)
     sigma = torch.relu(raw[..., 3])
     c = torch.sigmoid(raw[..., :3])
     delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 1e9, dtype=z.dtype)], -1)
@@ -118,18 +201,18 @@ def _sample_pdf(w, z, u):
 
 
 def train_forward(pc, pf, rays_o, rays_d, target, near, far, u_c, u_f, n_xyz=5, n_dir=4, n_angles=2,
-                  alpha=0.05, sampler_grad=True, dtype=torch.float64):
+                  alpha=0.05, sampler_grad=True, dtype=torch.float64, fp16_loss_scale=None):
     """-> (loss, mse_coarse, mse_fine|None, z_fine|None) as torch scalars/tensors (graph attached)."""
     o = torch.tensor(np.asarray(rays_o), dtype=dtype)
     d = torch.tensor(np.asarray(rays_d), dtype=dtype)
     tgt = torch.tensor(np.asarray(target), dtype=dtype)
     z = torch.tensor(O.get_z_values(near, far, np.asarray(u_c, np.float32)), dtype=dtype)
-    rgb_c, w_c = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha)
+    rgb_c, w_c = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha, fp16_loss_scale)
     mse_c = ((rgb_c - tgt) ** 2).mean()
     loss, mse_f, z_f = mse_c, None, None
     if pf is not None:
         z_f = _sample_pdf(w_c if sampler_grad else w_c.detach(), z, torch.tensor(np.asarray(u_f), dtype=dtype))
-        rgb_f, _ = _render_rays(pf, o, d, z_f, n_xyz, n_dir, n_angles, alpha)
+        rgb_f, _ = _render_rays(pf, o, d, z_f, n_xyz, n_dir, n_angles, alpha, fp16_loss_scale)
         mse_f = ((rgb_f - tgt) ** 2).mean()
         loss = loss + mse_f
     return loss, mse_c, mse_f, z_f
@@ -139,7 +222,8 @@ def train_gradients(blob_c, blob_f, rays_o, rays_d, target, near, far, u_c, u_f,
     """-> dict(loss, psnr_coarse, psnr_fine, grad_coarse (blob), grad_fine (blob|None), z_fine)."""
     shape_kw = {k: kw[k] for k in ("n_pos_enc_xyz", "n_pos_enc_dir", "n_angles") if k in kw}
     fw = dict(n_xyz=kw.get("n_pos_enc_xyz", 5), n_dir=kw.get("n_pos_enc_dir", 4), n_angles=kw.get("n_angles", 2),
-              alpha=kw.get("alpha", 0.05), sampler_grad=kw.get("sampler_grad", True), dtype=dtype)
+              alpha=kw.get("alpha", 0.05), sampler_grad=kw.get("sampler_grad", True), dtype=dtype,
+              fp16_loss_scale=kw.get("fp16_loss_scale"))        # not None: the library's mixed_float16 arithmetic
     pc = blob_to_params(blob_c, dtype, **shape_kw)
     pf = blob_to_params(blob_f, dtype, **shape_kw) if blob_f is not None else None
     loss, mse_c, mse_f, z_f = train_forward(pc, pf, rays_o, rays_d, target, near, far, u_c, u_f, **fw)

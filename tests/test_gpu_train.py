@@ -517,8 +517,8 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
         gradients non-finite -> that step is SKIPPED (weights unchanged) and the scale halves."""
     from oracle import train_oracle as T
     p = _problem(oracle, golden_ckpt)
-    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"],
-                          sampler_grad=True, alpha=1.0)
+    args = (p["bc"], p["bf"], p["o"], p["d"], p["tgt"], p["near"], p["far"], p["u_c"], p["u_f"])
+    r = T.train_gradients(*args, sampler_grad=True, alpha=1.0)
     grads = {}
     for scale in (32768.0, 4096.0):
         ctx = _ctx(p, leaky_relu_alpha=1.0)
@@ -529,13 +529,32 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
         assert np.isfinite(gc).all() and np.isfinite(gf).all()
         ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
         cc, cf = _cos(gc, r["grad_coarse"]), _cos(gf, r["grad_fine"])
+        # ... and against the autograd oracle that rounds where the kernels round (oracle/train_oracle.py::_mlp16: fp16
+        # operands, fp16 stash, row-scaled fp16 gradient operands, fp16 D carrying this loss scale).  The float64 figure
+        # for the coarse network is the inverse-CDF sampler's 1e5 gain (its 1e-5 clamp) acting on the FORWARD's fp16
+        # rounding -- the emulation reproduces the same 1.1e-1 against float64 -- so the emulation, which shares the
+        # forward rounding, is what tests the fp16 backward chain through the sampler term.
+        r16 = T.train_gradients(*args, sampler_grad=True, alpha=1.0, fp16_loss_scale=scale)
+        qc, qf = _relerr(gc, r16["grad_coarse"]), _relerr(gf, r16["grad_fine"])
         with capsys.disabled():
             print(f"\n[mixed_float16, loss scale {scale:g}] gradients vs float64 autograd: coarse {ec:.2e}, fine {ef:.2e} "
-                  f"of max|g|; cosine {cc:.5f}, {cf:.5f}", end="")
-        # measured: fine 4.7e-3 / cosine 0.99996; coarse 1.1e-1 / 0.9998 -- the coarse gradient is dominated by the
-        # sampler term, whose inverse-CDF interpolation has gains of 1e5 (its 1e-5 clamp) on fp16-class weights
+                  f"of max|g|; cosine {cc:.5f}, {cf:.5f}; vs the fp16-emulating autograd oracle: coarse {qc:.2e}, fine "
+                  f"{qf:.2e} (the emulation itself vs float64: coarse "
+                  f"{_relerr(r16['grad_coarse'], r['grad_coarse']):.2e}, fine {_relerr(r16['grad_fine'], r['grad_fine']):.2e})", end="")
         assert ef <= 2e-2 and cf > 0.9999 and ec <= 2e-1 and cc > 0.999
+        assert qc <= 3e-2 and qf <= 5e-3
+        assert abs(m["loss"] - r16["loss"]) <= 2e-5 * r16["loss"]
         ctx.close()
+    # sampler term off (classic NeRF): the coarse network sees only its own loss -- fp16 class against float64 directly
+    r0 = T.train_gradients(*args, sampler_grad=False, alpha=1.0)
+    ctx = _ctx(p, leaky_relu_alpha=1.0)
+    ctx.train_begin(5e-4, mixed_float16=True, sampler_gradient=False)
+    _, gc0, gf0 = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    ctx.close()
+    e0c, e0f = _relerr(gc0, r0["grad_coarse"]), _relerr(gf0, r0["grad_fine"])
+    with capsys.disabled():
+        print(f"\n[mixed_float16, sampler_gradient=False] vs float64 autograd: coarse {e0c:.2e}, fine {e0f:.2e} of max|g|", end="")
+    assert e0c <= 2e-2 and e0f <= 2e-2 and _cos(gc0, r0["grad_coarse"]) > 0.9999
     # a power-of-two loss scale changes nothing but which gradient entries leave fp16's normal range in the half-width
     # buffers: between two sane scales the unscaled gradients agree to fp16 class
     np.testing.assert_allclose(grads[32768.0][1], grads[4096.0][1], rtol=0, atol=2e-2 * np.abs(grads[4096.0][1]).max())

@@ -67,6 +67,13 @@ def test_colmap_loader_matches_fixture_constants(golden_ckpt):
     idx = N.get_train_images_indices(71, 19)
     assert len(idx) == 70 and 19 not in idx
     assert N.get_train_images_indices(71, 19, [0, 2, 19, 4]) == [0, 2, 4]
+    # load_llff_data returns the depth bounds per view, (n, 2) = (near, far) rows, as the reference does
+    # (src/UtilsFiles.py:113-114: transpose, then moveaxis(-1, 0)), scaled with the poses
+    _, poses_hwf, bounds, _, scale2 = N.load_llff_data(root)
+    raw = np.load(os.path.join(root, "poses_bounds.npy"), allow_pickle=False)
+    assert bounds.shape == (71, 2) and scale2 == scale
+    np.testing.assert_allclose(bounds, raw[:, 15:] * scale, rtol=1e-12)
+    assert (bounds[:, 0] < bounds[:, 1]).all()
 
 
 def test_blender_loader_semantics(tmp_path):
