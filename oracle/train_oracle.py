@@ -99,6 +99,7 @@ def _r16_rows(g: torch.Tensor) -> torch.Tensor:
     """The backward chain's operand packing: every sample row is scaled by its own power of two so that its largest entry
     lies in (2^5, 2^6], rounded to fp16 and scaled back (mlp_bwd_f16x3.hip::pow2_to_peak)."""
     m = g.detach().abs().amax(dim=-1, keepdim=True)
+    m = torch.where(m < 2.0 ** -120, torch.zeros_like(m), m)        # the kernels work in fp32: nothing lives below its range
     e = torch.where(m > 0, torch.ceil(torch.log2(torch.where(m > 0, m, torch.ones_like(m)))), torch.zeros_like(m))
     s = torch.pow(torch.full_like(m, 2.0), 6.0 - e)                   # m * s in (2^5, 2^6]
     return _r16(g * s) / s

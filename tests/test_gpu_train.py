@@ -508,8 +508,11 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
     """The reference's production policy (mixed_float16 + LossScaleOptimizer; src/ExecutionRun.py:220-221,262 and the
     loss-scaled branch src/NeRF.py:159-163) on the trainer:
       * gradients: fp16-class agreement with the float64 autograd oracle on the smooth alpha = 1 network (fine: 2e-2 of
-        max|g|, cosine > 0.9999; coarse, through the sampler: cosine > 0.999 -- the fp32 policy reaches 1e-5..1e-4 on
-        the same problem), loss within 1e-3 relative;
+        max|g|, cosine > 0.9999; coarse: cosine > 0.999 -- the fp32 policy reaches 1e-5..1e-4 on the same problem), loss
+        within 1e-3 relative; and TIGHT agreement (coarse 2e-2, measured 2.5e-3..6.5e-3) with the autograd oracle that
+        rounds where the kernels round (fp16 operands / stash / D buffers, row-scaled fp16 gradient operands), at alpha 1
+        and 0.05, with and without the sampler term: the float64 distance (1.1e-1 coarse at alpha 1, 3.4e-1 at alpha
+        0.05 with the sampler's 1e5 gain) is the arithmetic class, which the emulation shares, not a kernel error;
       * activations and pre-activation gradients live in fp16 (half the bytes of the fp32 policy's buffers), the latter
         carrying the loss scale as the policy's activation gradients do; two sane scales give the same gradients to fp16
         class;
@@ -542,19 +545,31 @@ def test_mixed_float16_policy_gradients_and_loss_scaling(oracle, golden_ckpt, ca
                   f"{qf:.2e} (the emulation itself vs float64: coarse "
                   f"{_relerr(r16['grad_coarse'], r['grad_coarse']):.2e}, fine {_relerr(r16['grad_fine'], r['grad_fine']):.2e})", end="")
         assert ef <= 2e-2 and cf > 0.9999 and ec <= 2e-1 and cc > 0.999
-        assert qc <= 3e-2 and qf <= 5e-3
+        assert qc <= 2e-2 and qf <= 2e-3                 # measured 6.5e-3 / 5.0e-4
         assert abs(m["loss"] - r16["loss"]) <= 2e-5 * r16["loss"]
         ctx.close()
-    # sampler term off (classic NeRF): the coarse network sees only its own loss -- fp16 class against float64 directly
-    r0 = T.train_gradients(*args, sampler_grad=False, alpha=1.0)
-    ctx = _ctx(p, leaky_relu_alpha=1.0)
-    ctx.train_begin(5e-4, mixed_float16=True, sampler_gradient=False)
-    _, gc0, gf0 = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
-    ctx.close()
-    e0c, e0f = _relerr(gc0, r0["grad_coarse"]), _relerr(gf0, r0["grad_fine"])
-    with capsys.disabled():
-        print(f"\n[mixed_float16, sampler_gradient=False] vs float64 autograd: coarse {e0c:.2e}, fine {e0f:.2e} of max|g|", end="")
-    assert e0c <= 2e-2 and e0f <= 2e-2 and _cos(gc0, r0["grad_coarse"]) > 0.9999
+    # The same comparison at the reference's alpha = 0.05 and with the sampler term off (classic NeRF).  Against float64
+    # the fp16 class shows as 1.5e-2 (sampler off) / 3.4e-1 (sampler on: the inverse-CDF interpolation's 1e5 gain, its
+    # 1e-5 clamp, acting on fp16-rounded coarse weights) of max|g| -- figures the EMULATION has against float64 too
+    # (oracle/train_oracle.py, CPU test test_fp16_emulation_explains_the_mixed_policy_error); what pins the kernels is the
+    # distance to the emulation.
+    for alpha, sg in ((0.05, True), (0.05, False), (1.0, False)):
+        r64 = T.train_gradients(*args, sampler_grad=sg, alpha=alpha)
+        r16 = T.train_gradients(*args, sampler_grad=sg, alpha=alpha, fp16_loss_scale=32768.0)
+        ctx = _ctx(p, leaky_relu_alpha=alpha)
+        ctx.train_begin(5e-4, mixed_float16=True, sampler_gradient=sg)
+        m, gc0, gf0 = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+        ctx.close()
+        qc, qf = _relerr(gc0, r16["grad_coarse"]), _relerr(gf0, r16["grad_fine"])
+        with capsys.disabled():
+            print(f"\n[mixed_float16, alpha {alpha:g}, sampler_gradient={sg}] vs float64 autograd: coarse "
+                  f"{_relerr(gc0, r64['grad_coarse']):.2e}, fine {_relerr(gf0, r64['grad_fine']):.2e}; vs the fp16-emulating "
+                  f"oracle: coarse {qc:.2e}, fine {qf:.2e}; cosine {_cos(gc0, r16['grad_coarse']):.6f}, "
+                  f"{_cos(gf0, r16['grad_fine']):.6f}", end="")
+        assert abs(m["loss"] - r16["loss"]) <= 1e-4 * r16["loss"]
+        # measured at alpha 0.05 with the sampler term: coarse 2.5e-3, fine 9.8e-3 (a few LeakyReLU sign flips of near-zero
+        # pre-activations: fp32 against float64 accumulation of the same fp16 products)
+        assert qc <= 2e-2 and qf <= 3e-2 and _cos(gc0, r16["grad_coarse"]) > 0.9999 and _cos(gf0, r16["grad_fine"]) > 0.9999
     # a power-of-two loss scale changes nothing but which gradient entries leave fp16's normal range in the half-width
     # buffers: between two sane scales the unscaled gradients agree to fp16 class
     np.testing.assert_allclose(grads[32768.0][1], grads[4096.0][1], rtol=0, atol=2e-2 * np.abs(grads[4096.0][1]).max())
