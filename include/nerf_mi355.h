@@ -182,7 +182,7 @@ typedef struct nerf_train_config {
      * gradients rounded to fp16 between layers, fp32 accumulation, fp32 master weights and weight gradients; the
      * loss is scaled before the backward pass, gradients are unscaled and tested: a step with a non-finite gradient is
      * SKIPPED and halves the scale, dynamic_growth_steps finite steps in a row double it (Keras 2.7 dynamic loss
-     * scaling: initial 2^15, growth interval 2000).  Not supported for the xyz-only network. */
+     * scaling: initial 2^15, growth interval 2000).  All three network variants (n_angles 2, 1, 0). */
     int32_t mixed_float16;
     float initial_loss_scale;      /* 0 -> 32768 */
     int32_t dynamic_growth_steps;  /* 0 -> 2000 */

@@ -61,8 +61,8 @@ constexpr int kBFStreamChunksDx = kBFChunksHead + 6 * kBFChunksHid + kBFChunksHi
 
 constexpr int kBConstWrgb = 2208;     // the forward kernel's constant block is reused: [3][128] rgb head weights
 constexpr int kBConstFloats = 2608;
-constexpr int kBLdsGmax = kLdsConst + kBConstFloats * 4;   // 9 x uint32: max|D| bits per gradient buffer, then spare
-static_assert(kBConstFloats + 16 <= kConstFloats, "gmax slots must fit the shared LDS carve");
+constexpr int kBLdsGmax = kLdsConst + (kConstFloats - 16) * 4;   // 9 (xyz-only network: 10) x uint32: max|D| bits per gradient buffer
+static_assert(kBConstFloats + 16 <= kConstFloats && kXConstFloats + 16 <= kConstFloats, "gmax slots must fit the shared LDS carve");
 
 enum { BW_HEAD = 0, BW_HID = 1, BW_XYZ = 2 };
 
@@ -110,11 +110,15 @@ __device__ __forceinline__ float mask_select(int m, float neg, float pos) {
 // still have to move to xh/xl; after BW_HEAD (which writes xh/xl directly) they must not.
 // FAST = the mixed_float16 policy's arithmetic: one fp16 MFMA pass per product (hi fragments only, their own stream),
 // the masked gradient rounded (RNE) to fp16 as the next operand; the per-sample scales work as before.
-template <int KIND, int NX, bool PEND, bool FAST>
+// SIG / SIGP (the xyz-only network, src/NeRF.py:248-288: sigma = Dense(1)(h8) while the colour branch runs on through another
+// 256-wide layer): this body's / the previous body's hidden tiles are dL/dh8 = W8 . D8b + w_sigma * d_sigma -- the rank-1
+// term is added to the accumulator on the VALU (w_sigma from the constant block, d_sigma in the accumulator's scale).
+template <int KIND, int NX, bool PEND, bool FAST, bool SIG = false, bool SIGP = false>
 __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, BwdLane& L, bool copy_tail,
                                          float* d_prev, float* d_cur, float* dx_cur, const frag4& mk_prev,
                                          const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[4], frag4 (&xh)[16],
-                                         frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14]) {
+                                         frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14], float d_sigma = 0.f,
+                                         uint32_t cb_h = 0u) {
 #ifndef NERF_BWD_EXTRA_FAST
 #define NERF_BWD_EXTRA_FAST 0
 #endif
@@ -160,10 +164,21 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     const float ainv_prev = pinned(alpha * L.inv_prev), arho_prev = pinned(alpha * L.rho_prev);
     const float ainv_cur = pinned(alpha * L.inv_sig);
     float arho_cur = pinned(alpha * L.rho);           // renewed with L.rho (PEND bodies fix it at k-step 8 of tile 0)
-    auto hidden_reg = [&](auto htc, auto rc, float acc_v, const frag4& mk, float inv_s, float rho_s, float ainv_s,
-                          float arho_s, float* dst, auto to_x) {
+    // d_sigma in the scale of this body's / the previous body's accumulators (operand scale = 1 / inv)
+    const float dsig_cur = SIG ? d_sigma * pow2_inverse(L.inv_sig) : 0.f;
+    const float dsig_prev = SIGP ? d_sigma * pow2_inverse(L.inv_prev) : 0.f;
+    (void)dsig_cur; (void)dsig_prev;
+    auto hidden_reg = [&](auto htc, auto rc, float acc_in, const frag4& mk, float inv_s, float rho_s, float ainv_s,
+                          float arho_s, float* dst, auto to_x, auto sig_sel) {
         constexpr int ht = decltype(htc)::value;
         constexpr int r = decltype(rc)::value;
+        float acc_v = acc_in;
+        if constexpr (decltype(sig_sel)::value != 0) {
+            // feature 32 ht + 8 (r >> 2) + 4 h + (r & 3) of this lane (cb_h carries the 4 h)
+            extern __shared__ __attribute__((aligned(16))) char smem_[];
+            const float ws = *reinterpret_cast<const float*>(smem_ + cb_h + (kXConstWsig + 32 * ht + 8 * (r >> 2) + (r & 3)) * 4);
+            acc_v = fmaf(ws, decltype(sig_sel)::value == 1 ? dsig_cur : dsig_prev, acc_in);
+        }
         // t = acc * LeakyReLU' / scale-in (the true value), pk = acc * LeakyReLU' * scale-out (the next operand): LeakyReLU'
         // is folded into the two power-of-two scales (exact), one selected factor each -- bfe + 2 bfi + 2 mul where
         // and + compare + select + three multiplications were 6 VALU ops per value
@@ -270,15 +285,19 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             if constexpr (u == 0 && PEND) {
                 if constexpr (n < 8) {           // previous body's hidden tile 7, a register pair per k-step
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                               mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{});
+                               mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{},
+                               std::integral_constant<int, SIGP ? 2 : 0>{});
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n + 1>{},
-                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{});
+                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{},
+                               std::integral_constant<int, SIGP ? 2 : 0>{});
                 }
                 if constexpr (n == 8) {
                     // this body's operand is complete: its peak fixes the scale of this body's outputs, and (in true
                     // scale) is max|D| of the buffer the previous body wrote
                     const float m_in = max_with_other_half(L.mrun);
-                    L.rho = pow2_to_peak(m_in);
+                    // (SIG: this body's outputs also carry w_sigma * d_sigma, whose size is unrelated to the operand's --
+                    // with only the operand's peak a ray whose colour gradient vanishes overflowed the fp16 packing)
+                    L.rho = pow2_to_peak(SIG ? fmaxf(m_in, fabsf(dsig_cur)) : m_in);
                     arho_cur = pinned(alpha * L.rho);
                     L.mrun = 0.f;
                     atomicMax(lds_gmax() + gslot_prev, __float_as_uint(m_in * L.inv_sig));
@@ -294,13 +313,15 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                     constexpr int ht = pt - NX;
                     if constexpr (NSTEP >= 16) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, n>{}, prv[n], mk_cur,
-                                   L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                                   L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
+                                   std::integral_constant<int, SIG ? 1 : 0>{});
                     } else if constexpr (n < 8) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                                   mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{});
+                                   mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
+                                   std::integral_constant<int, SIG ? 1 : 0>{});
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n + 1>{},
                                    prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur,
-                                   std::integral_constant<bool, KIND == BW_HEAD>{});
+                                   std::integral_constant<bool, KIND == BW_HEAD>{}, std::integral_constant<int, SIG ? 1 : 0>{});
                     }
                 }
             }
@@ -320,8 +341,9 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     p.ck += 1;
 }
 
-template <bool DX, bool FAST>
+template <bool DX, bool FAST, bool XYZ = false>
 __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
+    constexpr int NMQ = XYZ ? 10 : 9;           // mask records / gradient buffers of the network
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -334,14 +356,15 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     const long long ntiles = a.Mp / 128;
     if ((long long)blockIdx.x >= ntiles) return;
 
-    for (int i = tid; i < kBConstFloats / 4; i += 256)
+    for (int i = tid; i < (XYZ ? kXConstFloats : kBConstFloats) / 4; i += 256)
         reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + kBLdsGmax)[tid] = 0u;
 
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = FAST ? (DX ? kBFStreamChunksDx : kBFStreamChunks) : (DX ? kBStreamChunksDx : kBStreamChunks);
+    p.n_chunks = (FAST ? (DX ? kBFStreamChunksDx : kBFStreamChunks) : (DX ? kBStreamChunksDx : kBStreamChunks)) +
+                 (XYZ ? (FAST ? kBFChunksHid : kBChunksHid) : 0);     // the xyz-only network has one more 256 x 256 body
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (kBCQ / 4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (kBCQ / 4 * kQuadBytes);
@@ -367,10 +390,11 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         const long long off128 = (m - j) * a.ld9 + (h * 32 + j) * 4; // this lane's slot in the fragment-major G9 rows
         // everything this tile reads from HBM, in one batch (a compiler-placed vmcnt wait drains the DMA ring once)
         const f32x4 graw = *reinterpret_cast<const f32x4*>(a.graw + m * 4);
-        frag4 mq[9];
+        frag4 mq[NMQ];
 #pragma unroll
-        for (int l = 0; l < 9; ++l) mq[l] = *(reinterpret_cast<const frag4*>(a.mask_ptr[8 - l]) + m * 2 + h);
-        // mq[0] = mask of h9 (layer 8's output), mq[1] = h8, ..., mq[8] = h1 (layer 0's output)
+        for (int l = 0; l < NMQ; ++l) mq[l] = *(reinterpret_cast<const frag4*>(a.mask_ptr[NMQ - 1 - l]) + m * 2 + h);
+        // mq[0] = mask of h9 (layer 8's output), mq[1] = h8, ..., mq[8] = h1 (layer 0's output); the xyz-only network has
+        // its extra layer's record at mq[1] and everything else one further down
 
         // ---- rgb head backward on the VALU: G9 = (W9 . d_rgb) * LeakyReLU'(h9), in fragment (k) order ----
         float g9[64];
@@ -380,9 +404,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             const int t = n >> 1, s = n & 1;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const f32x4 w0 = lds_read4(cb_h + (kBConstWrgb + 0 * 128 + 32 * t + 16 * s + 8 * g) * 4);
-                const f32x4 w1 = lds_read4(cb_h + (kBConstWrgb + 1 * 128 + 32 * t + 16 * s + 8 * g) * 4);
-                const f32x4 w2 = lds_read4(cb_h + (kBConstWrgb + 2 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                constexpr int kWrgb = XYZ ? kXConstWrgb : kBConstWrgb;
+                const f32x4 w0 = lds_read4(cb_h + (kWrgb + 0 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                const f32x4 w1 = lds_read4(cb_h + (kWrgb + 1 * 128 + 32 * t + 16 * s + 8 * g) * 4);
+                const f32x4 w2 = lds_read4(cb_h + (kWrgb + 2 * 128 + 32 * t + 16 * s + 8 * g) * 4);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -394,15 +419,15 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     mt = fmaxf(mt, fabsf(v));
                 }
                 if constexpr (FAST)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[8]) + off128 + 32 * (32 * t + 16 * s + 8 * g)) =
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[NMQ - 1]) + off128 + 32 * (32 * t + 16 * s + 8 * g)) =
                         make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
                 else
-                    *reinterpret_cast<f32x4*>(a.d_ptr[8] + off128 + 32 * (32 * t + 16 * s + 8 * g)) = o;
+                    *reinterpret_cast<f32x4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s + 8 * g)) = o;
             }
         }
         mt = max_with_other_half(mt);
         atomicMax(lds_gmax() + 0, __float_as_uint(mt));
-        const float m_true = fmaxf(mt, fabsf(graw[3]));
+        const float m_true = XYZ ? mt : fmaxf(mt, fabsf(graw[3]));   // (xyz-only: d_sigma enters one body later)
         BwdLane L;
         const float sig = pow2_to_peak(m_true);
         L.inv_sig = pow2_inverse(sig);
@@ -427,8 +452,9 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         }
         {   // the sigma head's rank-1 term rides as a 9th k-step: element 0 of lane half 0 = d_sigma
             float h0, l0;
-            if constexpr (FAST) { h0 = h ? 0.f : graw[3] * sig; l0 = 0.f; }
-            else split_trunc(h ? 0.f : graw[3] * sig, h0, l0);
+            const float ds = XYZ ? 0.f : graw[3];      // xyz-only: this k-step multiplies zero weights
+            if constexpr (FAST) { h0 = h ? 0.f : ds * sig; l0 = 0.f; }
+            else split_trunc(h ? 0.f : ds * sig, h0, l0);
             nh[8] = frag4{pack_h2(h0, 0.f), 0u, 0u, 0u};
             nl[8] = frag4{pack_h2(l0, 0.f), 0u, 0u, 0u};
         }
@@ -440,36 +466,49 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             if constexpr (FAST) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.d_ptr[l]) + off256);
             else return a.d_ptr[l] + off256;
         };
-        float* d_cur = d_row(7);
+        float* d_cur = d_row(XYZ ? 8 : 7);
         const long long offx = (m - j) * kBwdXyzLd + (h * 32 + j) * 4;      // the dx rows are fragment-major as well
         float* dxa = DX ? a.dx_ptr[0] + offx : nullptr;
         float* dxb = DX ? a.dx_ptr[1] + offx : nullptr;
         frag4 mk_prev = mq[1], mk_cur = mq[1];
         bwd_body<BW_HEAD, 0, false, FAST>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
                                     nh, nl);
-#pragma unroll 1
-        for (int l = 7; l >= 1; --l) {         // body of layer l: consumes D_l, produces D_(l-1)
-            // rotate the per-lane scale state and the mask queue (mq[1] is always the mask of the operand just produced)
+        auto rotate = [&](int l_out) {
+            // the per-lane scale state and the mask queue (mq[1] is always the mask of the operand just produced)
             L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
             L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
             mk_prev = mk_cur;
 #pragma unroll
-            for (int i = 1; i < 8; ++i) mq[i] = mq[i + 1];
+            for (int i = 1; i < NMQ - 1; ++i) mq[i] = mq[i + 1];
             mk_cur = mq[1];
             d_prev = d_cur;
-            d_cur = d_row(l - 1);
-            const int gslot_prev = 8 - l;          // slot k <-> D_(8-k)
+            d_cur = d_row(l_out);
+        };
+        if constexpr (XYZ) {
+            // the extra layer's body: consumes D8b (pre-activation gradient of the 256-wide layer after h8), produces
+            // D7 = (W8 . D8b + w_sigma d_sigma) * LeakyReLU'(h8); the previous body was BW_HEAD (no staged tail to copy)
+            rotate(7);
+            bwd_body<BW_HID, 0, true, FAST, true, false>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 1,
+                                                         accs, xh, xl, nh, nl, graw[3], cb_h);
+        }
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {         // body of layer l: consumes D_l, produces D_(l-1)
+            rotate(l - 1);
+            const int gslot_prev = NMQ - 1 - l;    // slot k <-> d_ptr[NMQ - 1 - k]
             if (DX && l == 4)
                 bwd_body<BW_HID, DX ? 2 : 0, true, FAST>(p, lane16, alpha, L, true, d_prev, d_cur, dxa, mk_prev, mk_cur,
                                                    gslot_prev, accs, xh, xl, nh, nl);
+            else if (XYZ && l == 7)            // ... whose last tile (finished here) still needs the sigma term
+                bwd_body<BW_HID, 0, true, FAST, false, XYZ>(p, lane16, alpha, L, true, d_prev, d_cur, nullptr, mk_prev, mk_cur,
+                                                            gslot_prev, accs, xh, xl, nh, nl, graw[3], cb_h);
             else
-                bwd_body<BW_HID, 0, true, FAST>(p, lane16, alpha, L, l != 7, d_prev, d_cur, nullptr, mk_prev, mk_cur, gslot_prev,
+                bwd_body<BW_HID, 0, true, FAST>(p, lane16, alpha, L, XYZ || l != 7, d_prev, d_cur, nullptr, mk_prev, mk_cur, gslot_prev,
                                           accs, xh, xl, nh, nl);
         }
         L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
         L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
         if constexpr (DX) {
-            bwd_body<BW_XYZ, 2, true, FAST>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, 8, accs, xh, xl, nh, nl);
+            bwd_body<BW_XYZ, 2, true, FAST>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, NMQ - 1, accs, xh, xl, nh, nl);
         } else {
             // flush: D0's last tile has no chain to ride on; nothing is packed any more
             f32x16& last = accs[3];
@@ -492,12 +531,12 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);
-            atomicMax(lds_gmax() + 8, __float_as_uint(max_with_other_half(tmax)));
+            atomicMax(lds_gmax() + NMQ - 1, __float_as_uint(max_with_other_half(tmax)));
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < 9 && a.gmax) {
+    if (tid < NMQ && a.gmax) {
         const uint32_t v = reinterpret_cast<const uint32_t*>(smem + kBLdsGmax)[tid];
         unsigned* slot = a.gmax + 64 * tid + (blockIdx.x & 63);
         if (v > *slot) atomicMax(slot, v);
@@ -508,18 +547,26 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_kernel(const MlpBwdArgs 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, false>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true>(a); }
+// the xyz-only network (n_angles_for_model = 0): one more 256-wide body, sigma's rank-1 term one body later
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_xyz_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_xyz_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_xyz_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_xyz_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true, true>(a); }
 
-void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream) {
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream, bool xyz_only) {
     if (a.Mp <= 0) return;
     const long long ntiles = a.Mp / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    auto* k = single_pass ? (dx ? mlp_bwd_f16_dx_kernel : mlp_bwd_f16_kernel)
-                          : (dx ? mlp_bwd_f16x3_dx_kernel : mlp_bwd_f16x3_kernel);
+    auto* k = xyz_only ? (single_pass ? (dx ? mlp_bwd_f16_xyz_dx_kernel : mlp_bwd_f16_xyz_kernel)
+                                      : (dx ? mlp_bwd_f16x3_xyz_dx_kernel : mlp_bwd_f16x3_xyz_kernel))
+              : single_pass ? (dx ? mlp_bwd_f16_dx_kernel : mlp_bwd_f16_kernel)
+                            : (dx ? mlp_bwd_f16x3_dx_kernel : mlp_bwd_f16x3_kernel);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
 void mlp_bwd_f16x3_set_attributes() {
-    for (auto* k : {mlp_bwd_f16x3_kernel, mlp_bwd_f16x3_dx_kernel, mlp_bwd_f16_kernel, mlp_bwd_f16_dx_kernel})
+    for (auto* k : {mlp_bwd_f16x3_kernel, mlp_bwd_f16x3_dx_kernel, mlp_bwd_f16_kernel, mlp_bwd_f16_dx_kernel,
+                    mlp_bwd_f16x3_xyz_kernel, mlp_bwd_f16x3_xyz_dx_kernel, mlp_bwd_f16_xyz_kernel, mlp_bwd_f16_xyz_dx_kernel})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
@@ -530,10 +577,15 @@ void mlp_bwd_f16x3_set_attributes() {
 void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdStreamBytes / 2 entries */) {
     memset(idx, 0, (kBwdStreamBytes / 2) * sizeof(int32_t));
     const int kd = 256 + 8 * (n_angles + 1);
-    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
-                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
-    long long koff[11], off = 0;
-    for (int i = 0; i < 11; ++i) { koff[i] = off; off += (long long)shapes[i][0] * shapes[i][1] + shapes[i][1]; }
+    const bool xyz_only = n_angles == 0;
+    const int shapes_dir[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}, {0, 0}};
+    // get_network_only_xyz (src/NeRF.py:248-288): ..., 8: 256 -> 256, 9: 256 -> 128, 10: 128 -> 3, 11: 256 -> 1
+    const int shapes_xyz[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {256, 256}, {256, 128}, {128, 3}, {256, 1}};
+    const int (*shapes)[2] = xyz_only ? shapes_xyz : shapes_dir;
+    long long koff[12], off = 0;
+    for (int i = 0; i < 12; ++i) { koff[i] = off; off += (long long)shapes[i][0] * shapes[i][1] + shapes[i][1]; }
     size_t chunk = 0;
     // one body: NU tiles x NSTEP k-steps; src(u, i, n, e, h) gives the blob index of A[i][k] or -1
     auto emit = [&](int NU, int NSTEP, auto src) {
@@ -554,9 +606,11 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
                     }
         chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kBCQ - 1) / kBCQ;
     };
-    // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step)
+    // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step); xyz-only network: layer 9 (256 -> 128)
+    // transposed, the 9th k-step multiplies zeros (its sigma term is added one body later, on the VALU)
     emit(8, kBStepsHead, [&](int u, int i, int n, int e, int h) -> long long {
-        if (n < 8) return koff[8] + (long long)(32 * u + i) * 128 + frag_feature(n, e, h);
+        if (n < 8) return koff[xyz_only ? 9 : 8] + (long long)(32 * u + i) * 128 + frag_feature(n, e, h);
+        if (xyz_only) return -1;
         return (e == 0 && h == 0) ? koff[10] + (32 * u + i) : -1;
     });
     auto hidden = [&](int l, int row0) {
@@ -573,7 +627,7 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
             return koff[l] + (long long)(row0 + 32 * (u - nx) + i) * 256 + frag_feature(n, e, h);
         };
     };
-    for (int l = 7; l >= 5; --l) emit(8, 16, hidden(l, 0));
+    for (int l = xyz_only ? 8 : 7; l >= 5; --l) emit(8, 16, hidden(l, 0));
     if (dx) emit(10, 16, with_xyz(4, 2, kXyzDim));
     else emit(8, 16, hidden(4, kXyzDim));
     for (int l = 3; l >= 1; --l) emit(8, 16, hidden(l, 0));

@@ -89,7 +89,8 @@ constexpr int kXConstBias8 = 2080;    // 256: the extra hidden layer
 constexpr int kXConstBias9 = 2336;    // 128
 constexpr int kXConstWrgb = 2464;     // [3][128]
 constexpr int kXConstBHead = 2848;    // b_r, b_g, b_b, (unused)
-constexpr int kXConstFloats = 2864;
+constexpr int kXConstWsig = 2864;     // [256] the sigma head's weights as floats (the trainer's backward adds its rank-1 term on the VALU)
+constexpr int kXConstFloats = 3120;
 static_assert(kXConstFloats <= kConstFloats, "xyz-only constants must fit the shared LDS carve");
 enum { BODY_HIDSIG = 4, BODY_LAST0 = 5 };
 static_assert(kHConstFloats <= kConstFloats, "f16x3 constants must fit the shared LDS carve");

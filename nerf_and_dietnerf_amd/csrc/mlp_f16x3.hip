@@ -280,6 +280,17 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         f32x16& lastacc = accs[(NU - 1 + ROT) & 3];
 #pragma unroll
         for (int r = 0; r < 16; ++r) xc[(NU - 1) * 16 + r] = act(lastacc[r]);
+        if constexpr (STASH) {
+            static_for<0, 8>([&](auto pc) {
+                constexpr int r = 2 * decltype(pc)::value;
+                const float y0 = xc[(NU - 1) * 16 + r], y1 = xc[(NU - 1) * 16 + r + 1];
+                const uint32_t pp = pack_h2(y0, y1);
+                if constexpr (FAST) stash4h(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, r>{}, pp, st_cur);
+                else stash4(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, r>{}, y0, y1, st_cur);
+                mk_cur[(NU - 1) >> 1] = mask_push(mk_cur[(NU - 1) >> 1], pp);
+            });
+            if (mk_cur_ptr) *mk_cur_ptr = mk_cur;      // the 128-wide layer's record is complete
+        }
     }
     if constexpr (BODY == BODY_LAST) {
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
@@ -310,7 +321,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], frag4& hi, frag4& lo
 
 template <bool FAST, bool STASH = false, bool XYZ = false>
 __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
-    static_assert(!(STASH && XYZ), "the xyz-only network trains on the layer-wise path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -459,8 +469,16 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
             }
         }
         if constexpr (XYZ) {
-            layer_body_h<BODY_HIDSIG, true, FAST, false, 0>(p, lane16, cb_h, kXConstBiasSig * 4, a.alpha, nullptr, nullptr, nullptr, nullptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
-            layer_body_h<BODY_LAST0, true, FAST, false, 1>(p, lane16, cb_h, kXConstBias9 * 4, a.alpha, nullptr, nullptr, nullptr, nullptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            // (training: stash slot 8 = the extra 256-wide layer, slot 9 = the 128-wide one; each body finishes its
+            // predecessor's last tile, so the records rotate as above)
+            st_prev = st_cur; st_cur = st_of(8);
+            mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(8);
+            mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
+            layer_body_h<BODY_HIDSIG, true, FAST, STASH, 0>(p, lane16, cb_h, kXConstBiasSig * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
+            st_prev = st_cur; st_cur = st_of(9);
+            mk_prev_ptr = mk_cur_ptr; mk_cur_ptr = mk_of(9);
+            mk_prev = mk_cur; mk_cur = frag4{0u, 0u, 0u, 0u};
+            layer_body_h<BODY_LAST0, true, FAST, STASH, 1>(p, lane16, cb_h, kXConstBias9 * 4, a.alpha, st_prev, st_cur, mk_prev_ptr, mk_cur_ptr, mk_prev, mk_cur, accs, xh, xl, nh, nl, peh, pel, dh, dl, xc, sigma_raw);
         } else {
             st_prev = st_cur;
             st_cur = st_of(8);
@@ -515,11 +533,18 @@ __global__ __launch_bounds__(256, 1) void mlp_f16x3_stash_kernel(const MlpArgs a
 __global__ __launch_bounds__(256, 1) void mlp_f16_stash_kernel(const MlpArgs a) { mlp_f16_body<true, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16x3_xyz_kernel(const MlpArgs a) { mlp_f16_body<false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_f16_xyz_kernel(const MlpArgs a) { mlp_f16_body<true, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16x3_xyz_stash_kernel(const MlpArgs a) { mlp_f16_body<false, true, true>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_f16_xyz_stash_kernel(const MlpArgs a) { mlp_f16_body<true, true, true>(a); }
 
-void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass) {
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass, bool xyz_only) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 127) / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    if (xyz_only) {
+        if (single_pass) hipLaunchKernelGGL(mlp_f16_xyz_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+        else hipLaunchKernelGGL(mlp_f16x3_xyz_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+        return;
+    }
     if (single_pass) hipLaunchKernelGGL(mlp_f16_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
     else hipLaunchKernelGGL(mlp_f16x3_stash_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
@@ -556,6 +581,10 @@ void mlp_f16x3_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_xyz_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_xyz_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16x3_xyz_stash_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_xyz_stash_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
@@ -683,6 +712,7 @@ static void pack_f16_map(int n_angles, bool hi_only, EmitW emit_w, EmitC emit_c)
         for (int c = 0; c < 3; ++c)
             for (int f = 0; f < 128; ++f) emit_c(kXConstWrgb + c * 128 + f, L[10].k + f * 3 + c);
         for (int c = 0; c < 3; ++c) emit_c(kXConstBHead + c, L[10].b + c);
+        for (int f = 0; f < 256; ++f) emit_c(kXConstWsig + f, L[11].k + f);
         return;
     }
     emit_body(8, BODY_LAST);
@@ -710,9 +740,14 @@ static void pack_weights_f16_impl(const float* blob, int n_angles, void* stream_
 
 // gather tables of the 3-pass stream for the device-side re-pack (the trainer's forward runs on this kernel and its
 // weights change every step): stream_idx[slot] = 2 * (src + 1) + is_lo, const_idx[float] = src + 1; 0 = padding
-void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /*kStreamBytesF16[Hi] / 2*/,
+size_t f16_stream_bytes(int n_angles, bool hi_only) {
+    if (n_angles == 0) return hi_only ? kStreamBytesF16HiXyz : kStreamBytesF16Xyz;
+    return hi_only ? kStreamBytesF16Hi : kStreamBytesF16;
+}
+
+void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /* f16_stream_bytes / 2 */,
                         int32_t* const_idx /*kConstFloats*/) {
-    memset(stream_idx, 0, ((hi_only ? kStreamBytesF16Hi : kStreamBytesF16) / 2) * sizeof(int32_t));
+    memset(stream_idx, 0, (f16_stream_bytes(n_angles, hi_only) / 2) * sizeof(int32_t));
     memset(const_idx, 0, kConstFloats * sizeof(int32_t));
     pack_f16_map(n_angles, hi_only,
                  [&](long long ph, long long pl, long long src) {
@@ -745,8 +780,8 @@ __global__ void repack_f16x3_kernel(const float* __restrict__ blob, const int32_
 }
 
 void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
-                         bool hi_only, hipStream_t s) {
-    const size_t n = (hi_only ? kStreamBytesF16Hi : kStreamBytesF16) / 2;
+                         size_t stream_bytes, hipStream_t s) {
+    const size_t n = stream_bytes / 2;
     hipLaunchKernelGGL(repack_f16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blob, stream_idx,
                        reinterpret_cast<uint16_t*>(stream), const_idx, cst, n);
 }

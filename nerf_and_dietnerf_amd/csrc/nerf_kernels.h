@@ -48,7 +48,7 @@ constexpr int kConstWrgb = 2176;                    // [3][128]
 constexpr int kConstBHead = 2560;                   // b_r, b_g, b_b, b_sigma
 constexpr int kConstWsigH = 2564;                   // [256]  sigma head, hidden part
 constexpr int kConstWsigD = 2820;                   // [3][2][4] sigma head, dir part (g, half, e)
-constexpr int kConstFloats = 2880;                  // the LDS carve of the constants (largest user: the xyz-only f16 variant)
+constexpr int kConstFloats = 3136;                  // the LDS carve of the constants (largest user: the xyz-only trainer's backward: 3120 + 16 gmax slots)
 constexpr int kConstBytes = kConstFloats * 4;
 
 // LDS carve of the MLP kernel
@@ -68,12 +68,13 @@ struct MlpArgs {
     int S;                  // samples per ray (mode 0)
     int mode;
     float alpha;            // LeakyReLU slope
-    // training forward (mlp_f16x3 "stash" kernel only): where the fp32 activation of layer l = 0..8 is written,
-    // row-major with leading dimension st_ld[l] (rows padded to a multiple of 128); unused (null) when rendering
-    float* st_ptr[9];
-    int st_ld[9];
+    // training forward (mlp_f16x3 "stash" kernels only): where the activation of layer l = 0..8 (0..9 for the xyz-only
+    // network: ..., 8 = its extra 256-wide layer, 9 = the 128-wide one) is written, fragment-major with st_ld[l] elements
+    // per row (rows padded to a multiple of 128); unused (null) when rendering
+    float* st_ptr[10];
+    int st_ld[10];
     // ... and where the LeakyReLU' mask bits of layer l's output go: one uint4 per (row, lane half), see mlp_f16x3.hip
-    uint32_t* mask_ptr[9];
+    uint32_t* mask_ptr[10];
     int diag_wrap;          // diagnostic only (NERF_DIAG_STASH_WRAP=1): every workgroup's stash rows land in the first 8192 rows (cache-resident)
 };
 
@@ -87,12 +88,13 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStr
 // single_pass: hi*hi only; xyz_only: the 12-layer network without view directions (its own streams / constants)
 void launch_mlp_f16x3(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false, bool xyz_only = false);
 // forward that also writes a.st_ptr / a.mask_ptr (training); single_pass: the mixed_float16-class arithmetic
-void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false);
+void launch_mlp_f16x3_stash(const MlpArgs& a, int num_cus, hipStream_t stream, bool single_pass = false, bool xyz_only = false);
 // device-side re-pack of the 3-pass (or hi-only) stream + constants from a blob (tables from build_f16x3_gather, host)
-void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /*kStreamBytesF16[Hi]/2*/,
+size_t f16_stream_bytes(int n_angles, bool hi_only);     // kStreamBytesF16[Hi][Xyz]
+void build_f16x3_gather(int n_angles, bool hi_only, int32_t* stream_idx /* f16_stream_bytes / 2 */,
                         int32_t* const_idx /*kConstFloats*/);
 void launch_repack_f16x3(const float* blob, const int32_t* stream_idx, void* stream, const int32_t* const_idx, float* cst,
-                         bool hi_only, hipStream_t s);
+                         size_t stream_bytes, hipStream_t s);
 void mlp_f16x3_set_attributes();
 // stream_out: kStreamBytesF16 / kStreamBytesF16Hi bytes (kStreamBytesF16Xyz / kStreamBytesF16HiXyz when n_angles == 0)
 void pack_weights_f16x3(const float* blob, int n_angles, void* stream_out, float* const_out /*kConstFloats*/);
@@ -103,22 +105,25 @@ void launch_mlp_f16_2t(const MlpArgs& a, int num_cus, hipStream_t stream);
 void mlp_f16_2t_set_attributes();
 
 // mlp_bwd_f16x3.hip -- the trainer's fused data-gradient chain (the stash forward's counterpart)
-constexpr size_t kBwdStreamBytes = size_t(65) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles
+constexpr size_t kBwdStreamBytes = size_t(73) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles (73 chunks: the xyz-only network's)
 constexpr int kBwdXyzLd = 64;                                      // floats per row of an encoding-gradient buffer
 struct MlpBwdArgs {
     const void* wstream;     // backward operand stream of one network (build_bwd_gather / launch_repack_bwd)
     const float* wconst;     // the forward kernel's constant block (rgb head weights are read from it)
     const float* graw;       // (Mp, 4) gradient w.r.t. the raw network output [r, g, b, sigma]; padding rows zero
-    const uint32_t* mask_ptr[9];   // LeakyReLU' bit records of layers 0..8, written by the stash forward
-    float* d_ptr[9];         // d_ptr[l], l = 0..7: (Mp, 256) gradient w.r.t. layer l's pre-activation; d_ptr[8]: G9 (Mp, 128)
+    const uint32_t* mask_ptr[10];  // LeakyReLU' bit records of layers 0..8 (0..9: xyz-only network), written by the stash forward
+    float* d_ptr[10];        // d_ptr[l], l = 0..7: (Mp, 256) gradient w.r.t. layer l's pre-activation; d_ptr[8]: G9 (Mp, 128)
+                             // xyz-only network: d_ptr[8] = (Mp, 256) of its extra layer, d_ptr[9] = (Mp, 128) of the last one
     float* dx_ptr[2];        // dx variant: (Mp, 64) gradient w.r.t. the xyz encoding through layer 4 / through layer 0
-    unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k)
+    unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k); xyz-only
+                             // network: 10 groups, group 0 = d_ptr[9], group k = d_ptr[9 - k]
     long long Mp;            // rows, multiple of 128
     float alpha;
     int ld, ld9;             // row pitch (floats) of d_ptr[0..7] / d_ptr[8]
 };
 // single_pass: hi*hi products only, gradients rounded to fp16 between layers (the mixed_float16 policy's backward)
-void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream);
+void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream,
+                          bool xyz_only = false);
 void mlp_bwd_f16x3_set_attributes();
 void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdStreamBytes / 2 */);
 void launch_repack_bwd(const float* blob, const int32_t* idx, void* stream, hipStream_t s);

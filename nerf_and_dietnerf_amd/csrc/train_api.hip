@@ -28,6 +28,7 @@ struct TLayer {
 struct TNet {
     bool present = false;
     bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
+    bool mats_dirty = false;       // ... nor into the padded matrices of the layer-wise path (fused trainer skips them)
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
     void* fstream = nullptr;       // fused forward (f16x3 stash kernel): operand stream + constants, re-packed on device
     float* fcst = nullptr;
@@ -41,7 +42,7 @@ struct TPass {                      // activations of one pass, kept from forwar
     DevBuf C4, C8, H1, H2, H3, H5, H6, H7, H8b, H9, raw, T, w, rgb, z;   // H8b: xyz-only network's extra layer
     // fused backward: LeakyReLU' bit records of layers 0..8 (32 B per row and layer, written by the stash forward),
     // the pre-activation gradients D[0..7] (Mp x 256) and G9 = D[8] (Mp x 128), the two encoding-gradient parts
-    DevBuf masks, D[9], dxa, dxb;
+    DevBuf masks, D[10], dxa, dxb;     // D[8], D[9]: see MlpBwdArgs::d_ptr (the xyz-only network has ten gradient buffers)
 };
 
 struct TrainState {
@@ -102,13 +103,16 @@ int layer_table(const nerf_config& cfg, TLayer L[12]) {
 
 void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
-int relayout_net(nerf_ctx* c, TNet& n) {
+int relayout_net(nerf_ctx* c, TNet& n, bool force_mats = false) {
     if (n.fstream)
-        launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst, c->train->mixed, c->stream);
+        launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst,
+                            f16_stream_bytes(c->cfg.n_angles, c->train->mixed), c->stream);
     if (n.bstream) launch_repack_bwd(n.blob, c->train->bidx[n.bdx ? 1 : 0], n.bstream, c->stream);
     // the padded W / W^T / hi-lo planes feed the layer-wise GEMMs only; the fused forward + backward read the two
-    // re-packed streams above and nothing else (22 launches per step that nobody read)
-    if (c->train->training && c->train->frag) { HIP_OK(hipGetLastError()); return 0; }
+    // re-packed streams above and nothing else (22 launches per step that nobody read).  The xyz-only network's exact-fp32
+    // render mode does read them (layerwise_forward): they are brought up to date there, on demand.
+    if (c->train->training && c->train->frag && !force_mats) { n.mats_dirty = true; HIP_OK(hipGetLastError()); return 0; }
+    n.mats_dirty = false;
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
@@ -136,14 +140,14 @@ int alloc_optimizer(nerf_ctx* c, TrainState* t, TNet& n) {
 int ensure_fused(nerf_ctx* c, TrainState* t, TNet& n) {
     if (!t->fused_forward) return 0;
     if (!t->sidx) {
-        std::vector<int32_t> si(kStreamBytesF16 / 2), ci(kConstFloats);       // (the hi-only table uses its first half)
+        std::vector<int32_t> si(f16_stream_bytes(c->cfg.n_angles, t->mixed) / 2), ci(kConstFloats);
         build_f16x3_gather(c->cfg.n_angles, t->mixed, si.data(), ci.data());
         HIP_OK(hipMalloc((void**)&t->sidx, si.size() * sizeof(int32_t)));
         HIP_OK(hipMalloc((void**)&t->cidx, ci.size() * sizeof(int32_t)));
         HIP_OK(hipMemcpy(t->sidx, si.data(), si.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(t->cidx, ci.data(), ci.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (!n.fstream) HIP_OK(hipMalloc(&n.fstream, kStreamBytesF16));
+    if (!n.fstream) HIP_OK(hipMalloc(&n.fstream, kStreamBytesF16Xyz));     // the largest of the four streams
     if (!n.fcst) HIP_OK(hipMalloc((void**)&n.fcst, kConstBytes));
     if (t->fused_backward && t->training) {
         // the fine network's chain also produces the gradient w.r.t. the xyz encoding when the sampler is differentiated
@@ -202,16 +206,18 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
     const int ldh = c->train ? c->train->ldh : 256, ldh9 = c->train ? c->train->ldh9 : 128;
     for (DevBuf* h : hs) r |= ensure(c, *h, d.Mp * ldh * ea);
     r |= ensure(c, p.H9, d.Mp * ldh9 * ea);
-    if (c->cfg.n_angles == 0) r |= ensure(c, p.H8b, d.Mp * 256 * f);
+    if (c->cfg.n_angles == 0) r |= ensure(c, p.H8b, d.Mp * 256 * f);      // (fp32-sized: also the layer-wise path's)
     r |= ensure(c, p.raw, d.Mp * 4 * f);
     r |= ensure(c, p.T, d.M * f);
     r |= ensure(c, p.w, d.M * f);
     r |= ensure(c, p.rgb, d.N * 3 * f);
     r |= ensure(c, p.z, d.M * f);
     if (c->train && c->train->fused_backward && c->train->training) {
-        r |= ensure(c, p.masks, (size_t)9 * d.Mp * 32);
+        const bool xyz = c->cfg.n_angles == 0;
+        r |= ensure(c, p.masks, (size_t)(xyz ? 10 : 9) * d.Mp * 32);
         for (int l = 0; l < 8; ++l) r |= ensure(c, p.D[l], d.Mp * ldh * ea);
-        r |= ensure(c, p.D[8], d.Mp * ldh9 * ea);
+        r |= ensure(c, p.D[8], d.Mp * (xyz ? ldh : ldh9) * ea);
+        if (xyz) r |= ensure(c, p.D[9], d.Mp * ldh9 * ea);
         r |= ensure(c, p.dxa, d.Mp * kBwdXyzLd * f);
         r |= ensure(c, p.dxb, d.Mp * kBwdXyzLd * f);
     }
@@ -267,17 +273,19 @@ int forward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, const
         a.wstream = (const float*)n.fstream; a.wconst = n.fcst;
         a.in_a = o; a.in_b = dirs; a.z = z; a.raw = raw; a.nonfinite = c->nonfinite;
         a.M = d.M; a.S = d.S; a.mode = 0; a.alpha = c->cfg.leaky_relu_alpha;
-        float* dst[9] = {(float*)p.H1.p, (float*)p.H2.p, (float*)p.H3.p, (float*)p.C4.p, (float*)p.H5.p,
-                         (float*)p.H6.p, (float*)p.H7.p, (float*)p.C8.p, (float*)p.H9.p};
-        const int ld[9] = {t->ldh, t->ldh, t->ldh, kLdC4, t->ldh, t->ldh, t->ldh, kLdC8, t->ldh9};
-        for (int i = 0; i < 9; ++i) {
+        const bool xyz = c->cfg.n_angles == 0;
+        float* dst[10] = {(float*)p.H1.p, (float*)p.H2.p, (float*)p.H3.p, (float*)p.C4.p, (float*)p.H5.p,
+                          (float*)p.H6.p, (float*)p.H7.p, (float*)p.C8.p, xyz ? (float*)p.H8b.p : (float*)p.H9.p,
+                          xyz ? (float*)p.H9.p : nullptr};
+        const int ld[10] = {t->ldh, t->ldh, t->ldh, kLdC4, t->ldh, t->ldh, t->ldh, kLdC8, xyz ? t->ldh : t->ldh9, t->ldh9};
+        for (int i = 0; i < (xyz ? 10 : 9); ++i) {
             a.st_ptr[i] = dst[i]; a.st_ld[i] = ld[i];
             a.mask_ptr[i] = p.masks.p ? (uint32_t*)p.masks.p + (size_t)i * d.Mp * 8 : nullptr;
         }
 #ifdef NERF_DIAG_STASH_WRAP   // diagnostic BUILD only (make EXTRA=-DNERF_DIAG_STASH_WRAP): timing without HBM stores, wrong results
         a.diag_wrap = d.Mp >= 8192;
 #endif
-        launch_mlp_f16x3_stash(a, c->num_cus, c->stream, t->mixed);
+        launch_mlp_f16x3_stash(a, c->num_cus, c->stream, t->mixed, xyz);
     } else {
         forward_layers(c, n, p, d.Mp, raw);
     }
@@ -302,8 +310,11 @@ void wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     if (q.gemm.n == 0) return;
     int units = 0;
     for (int e = 0; e < q.gemm.n; ++e) units += (q.gemm.e[e].Kp + 255) / 256 * ((q.gemm.e[e].Nw + 255) / 256);
-    // one 512-thread workgroup per CU: two full rounds of the chip (every workgroup streams the same number of rows)
-    const int want_splits = std::max(8, 2 * c->num_cus / units);
+    // one 512-thread workgroup per CU, workgroups dealt round-robin to the 8 XCDs: a multiple of 8 slabs per layer such
+    // that no XCD gets more than two rounds of its 32 CUs (10 units x 51 slabs put 70 workgroups on three of the XCDs:
+    // a third round, +47 % on the launch)
+    const int per_xcd = std::max(1, 2 * (c->num_cus / 8) / units);
+    const int want_splits = 8 * per_xcd;
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 31) / 32 * 32;
     const int splits = (int)((Mp + rps - 1) / rps);
@@ -410,29 +421,43 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         b.wstream = n.bstream; b.wconst = n.fcst; b.graw = Graw; b.gmax = gm; b.Mp = Mp; b.alpha = c->cfg.leaky_relu_alpha;
         b.ld = t->ldh; b.ld9 = t->ldh9;
         const int ldh = t->ldh, ldh9 = t->ldh9;
-        for (int l = 0; l < 9; ++l) {
+        const bool xyz = n.n_layers == 12;
+        const int nrec = xyz ? 10 : 9;                   // mask records / gradient buffers; gmax group k <-> d_ptr[nrec - 1 - k]
+        for (int l = 0; l < nrec; ++l) {
             b.mask_ptr[l] = (const uint32_t*)p.masks.p + (size_t)l * Mp * 8;
             b.d_ptr[l] = (float*)p.D[l].p;
         }
         b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
-        launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream);
-        wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
-        wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-        wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0));
+        launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream, xyz);
         WgradQueue wq;
-        wq.open = t->wgrad_wide;
-        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(1), &wq);
-        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(2), &wq);
-        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(3), &wq);
-        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(4), &wq);
-        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(5), &wq);
-        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(6), &wq);
-        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(7), &wq);
+        if (xyz) {
+            // get_network_only_xyz (src/NeRF.py:248-288): 10 = the rgb head on h9, 11 = the sigma head on h8 (the first 256
+            // columns of C8), 9 = 256 -> 128 on the extra layer's output, 8 = that extra 256 -> 256 layer on h8
+            float* H8b = (float*)p.H8b.p;
+            wgrad(c, t, n, 10, H9, ldh9, Graw, 4, 4, 0, Mp);
+            wgrad(c, t, n, 11, C8, kLdC8, Graw, 4, 4, 3, Mp);
+            wgrad(c, t, n, 9, H8b, ldh, b.d_ptr[9], ldh9, 128, 0, Mp, GM(0));
+            wq.open = t->wgrad_wide;
+            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh, 256, 0, Mp, GM(1), &wq);
+        } else {
+            wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
+            wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
+            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0));
+            wq.open = t->wgrad_wide;
+        }
+        const int g0 = xyz ? 1 : 0;                      // gmax group of D_l is g0 + 8 - l
+        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(g0 + 1), &wq);
+        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(g0 + 2), &wq);
+        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(g0 + 3), &wq);
+        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(g0 + 4), &wq);
+        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(g0 + 5), &wq);
+        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(g0 + 6), &wq);
+        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(g0 + 7), &wq);
         // (the xyz encoding's columns 256.. of C4: in the fragment-major buffer a column offset c is 32 c ELEMENTS --
         // half the byte offset under the fp16 policy)
         const size_t xyz_off = (size_t)32 * 256;
         const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
-        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(8), &wq);
+        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(g0 + 8), &wq);
         wgrad_flush(c, t, wq, Mp);
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
@@ -773,6 +798,8 @@ int layerwise_forward(nerf_ctx* c, int which, const float* in_a, const float* in
                       long long M, int S, int mode) {
     TrainState* t = c->train;
     if (!t || !t->net[which].present) return fail("network %d has no weights loaded", which);
+    if (t->net[which].mats_dirty)          // the fused trainer does not keep the padded matrices current
+        if (int r = relayout_net(c, t->net[which], true)) return r;
     constexpr long long kChunk = 1 << 17;
     const long long cap = M < kChunk ? (M + 127) / 128 * 128 : kChunk;
     PassDims d{0, S, cap, cap};
@@ -826,7 +853,6 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     t->cfg = *cfg;
     t->training = true;
     t->mixed = cfg->mixed_float16 != 0;
-    if (t->mixed && c->cfg.n_angles == 0) { train_free(c); return fail("mixed_float16 training is not built for the xyz-only network"); }
     {
         OptState h{};
         h.scale = t->mixed ? (cfg->initial_loss_scale > 0.f ? cfg->initial_loss_scale : 32768.f) : 1.f;
@@ -842,7 +868,7 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // forward on the fused kernel unless the network has no fused kernel (xyz-only) or NERF_TRAIN_FORWARD=gemm asks
     // for the layer-wise fp32 GEMM forward (exact fp32 products instead of the 3-pass split)
     const char* fw = getenv("NERF_TRAIN_FORWARD");
-    t->fused_forward = c->cfg.n_angles != 0 && !(fw && strcmp(fw, "gemm") == 0);
+    t->fused_forward = !(fw && strcmp(fw, "gemm") == 0);
     // weight gradients on the fp16 matrix cores (split operands, fp32-class) unless NERF_TRAIN_WGRAD=fp32
     const char* wg = getenv("NERF_TRAIN_WGRAD");
     t->wgrad_f16 = !(wg && strcmp(wg, "fp32") == 0);

@@ -113,17 +113,19 @@ class _Dense16(torch.autograd.Function):
     store16 = False: the heads, whose weight gradients read the fp32 gradient of the raw outputs (head_wgrad)."""
 
     @staticmethod
-    def forward(ctx, x_q, w, b, loss_scale, store16):
+    def forward(ctx, x_q, w, b, loss_scale, store16, valu_data_grad=False):
         w_q = _r16(w)
-        ctx.save_for_backward(x_q, w_q)
-        ctx.ls, ctx.store16 = loss_scale, store16
+        ctx.save_for_backward(x_q, w_q, w)
+        ctx.ls, ctx.store16, ctx.valu = loss_scale, store16, valu_data_grad
         return x_q @ w_q + b
 
     @staticmethod
     def backward(ctx, g):
-        x_q, w_q = ctx.saved_tensors
+        x_q, w_q, w = ctx.saved_tensors
         g_st = _r16(g * ctx.ls) / ctx.ls if ctx.store16 else g
-        return _r16_rows(g) @ w_q.t(), x_q.t() @ g_st, g_st.sum(0), None, None
+        # valu_data_grad: the xyz-only network's sigma head, whose rank-1 data gradient is added in fp32 on the VALU
+        g_x = g @ w.t() if ctx.valu else _r16_rows(g) @ w_q.t()
+        return g_x, x_q.t() @ g_st, g_st.sum(0), None, None, None
 
 
 class _RgbHead16(torch.autograd.Function):
@@ -142,16 +144,21 @@ class _RgbHead16(torch.autograd.Function):
 
 
 def _mlp16(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float, loss_scale: float):
-    """_mlp under the library's mixed_float16 arithmetic (view-direction network)."""
+    """_mlp under the library's mixed_float16 arithmetic (view-direction network, or the xyz-only one: 24 tensors)."""
     lrelu = lambda t: torch.nn.functional.leaky_relu(t, alpha)
-    dense = lambda x, i, st=True: _Dense16.apply(x, p[2 * i], p[2 * i + 1], loss_scale, st)
-    xq, dq = _ste16(xyz_enc), _ste16(dir_enc)
+    dense = lambda x, i, st=True, valu=False: _Dense16.apply(x, p[2 * i], p[2 * i + 1], loss_scale, st, valu)
+    xq = _ste16(xyz_enc)
     h = _ste16(lrelu(dense(xq, 0)))
     for i in (1, 2, 3):
         h = _ste16(lrelu(dense(h, i)))
     h = _ste16(lrelu(dense(torch.cat([xq, h], -1), 4)))
     for i in (5, 6, 7):
         h = _ste16(lrelu(dense(h, i)))
+    if len(p) == 24:                                  # get_network_only_xyz, src/NeRF.py:265-287
+        h8b = _ste16(lrelu(dense(h, 8)))
+        y9 = lrelu(dense(h8b, 9))                     # stays fp32 for the VALU head
+        return torch.cat([_RgbHead16.apply(y9, p[20], p[21]), dense(h, 11, False, True)], -1)
+    dq = _ste16(dir_enc)
     hd = torch.cat([h, dq], -1)
     y9 = lrelu(dense(hd, 8))                                          # stays fp32 for the VALU head
     rgb = _RgbHead16.apply(y9, p[18], p[19])
@@ -168,8 +175,6 @@ def _render_rays(p, o, d, z, n_xyz, n_dir, n_angles, alpha, fp16_loss_scale=None
     view = d[:, comps][:, None, :].expand(n, s, len(comps)).reshape(-1, len(comps))
     dir_enc = None if n_angles == 0 else _pe(view, n_dir, False)     # UtilsNeuralRadianceField.py:205
     if fp16_loss_scale is not None:
-        if n_angles != 2:
-            raise NotImplementedError("the fp16 emulation restates the view-direction network")
         raw = _mlp16(p, _pe(pts, n_xyz, True), dir_enc, alpha, float(fp16_loss_scale)).reshape(n, s, 4)
     else:
         raw = _mlp(p, _pe(pts, n_xyz, True), dir_enc, alpha).reshape(n, s, 4)
