@@ -159,7 +159,11 @@ __device__ __forceinline__ void pipe_sync_c(Pipe& p) {
 #if defined(NERF_DIAG) && NERF_DIAG == 2
     asm volatile("" ::: "memory");
 #else
+#if defined(NERF_DIAG) && NERF_DIAG == 3   // timing-only diagnostic: DMA and barrier stay, the wait for the landing is dropped
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(NPIECE * (RING - 3) + EXTRA) : "memory");
+#endif
 #if !(defined(NERF_DIAG) && NERF_DIAG == 1)
     __builtin_amdgcn_s_barrier();
 #endif
