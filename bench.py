@@ -133,7 +133,7 @@ def main():
     if args.rehearse_world > 1 and world == 1:
         begin, count = N.ray_slab(total, 0, args.rehearse_world)
 
-    c_gather = args.c_gather and world > 1 and backend == "nccl"
+    c_gather = args.c_gather and world > 1 and (backend == "nccl" or bool(os.environ.get("NERF_RCCL_LIB")))
     if c_gather:
         model.ctx.comm_init_from_torch()
 
@@ -175,7 +175,9 @@ def main():
         return rgb
 
     gather_check = None
-    if world > 1 and backend == "nccl":
+    # (also under the one-GPU rehearsal -- BENCH_BACKEND=gloo with NERF_RCCL_LIB naming tests/stub_rccl.c's stand-in, the only
+    # way two ranks can share a device -- so that this check itself has run before the driver's first real N > 1 launch)
+    if world > 1 and (backend == "nccl" or os.environ.get("NERF_RCCL_LIB")):
         # the two assemblies of the frame (torch collective vs the library's own ncclAllGather) must agree bit for bit.
         # A mismatch fails the run loudly; a C-level communicator that cannot be created (it is a second RCCL
         # communicator beside torch's) is reported and the run goes on with the torch collective.
@@ -189,7 +191,7 @@ def main():
             a_img = None
             gather_check = f"c-level communicator unavailable ({type(e).__name__}: {e}); torch all-gather only"
         # every rank takes the same branch below (the comparison contains a collective): all or none
-        ok_all = torch.tensor([1 if a_img is not None else 0], dtype=torch.int32, device="cuda")
+        ok_all = torch.tensor([1 if a_img is not None else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
         if int(ok_all.item()) == 0 and a_img is not None:
             a_img = None
