@@ -847,3 +847,71 @@ def test_fp16_core_trainer_equals_exact_fp32_trainer_at_full_size(oracle, golden
             assert cc > 0.999
     with capsys.disabled():
         print("\n[fp16-core vs exact-fp32 trainer, 1024 rays x 192] " + "\n    ".join(lines))
+
+
+@pytest.mark.parametrize("n_angles", [0, 1])
+def test_backward_through_render_and_mixed_policy_for_the_other_network_variants(oracle, n_angles, capsys):
+    """The two less common network variants on the fused trainer (round 3: n_angles = 0 has its own kernels; n_angles = 1
+    shares the view-direction kernels with zero-packed rows): backward through NeRF.render (src/NeRF.py:109-134, DietNeRF's
+    graph) against float64 autograd under the float32 policy, and train_step gradients under mixed_float16 against the
+    fp16-emulating oracle."""
+    from oracle import train_oracle as T
+    import nerf_and_dietnerf_amd as N
+    n, sc, sf = 24, 16, 20
+    o, d, rng = _rays(oracle, n, 11)
+    u_c, u_f = rng.random((n, sc), dtype=np.float32), rng.random((n, sf), dtype=np.float32)
+    d_rgb = (rng.standard_normal((n, 3)) * 1e-2).astype(np.float32)
+    tgt = rng.random((n, 3), dtype=np.float32)
+    kw = dict(n_pos_enc_xyz=5, n_pos_enc_dir=4, n_angles=n_angles)
+    bc, bf = N.glorot_blob(31, n_angles=n_angles), N.glorot_blob(32, n_angles=n_angles)
+    bc[-1] = bf[-1] = 1.5
+    near, far = 0.5, 2.5
+    ctx = N.Context(near=near, far=far, n_angles=n_angles, leaky_relu_alpha=1.0)
+    ctx.load_weights(0, bc)
+    ctx.load_weights(1, bf)
+    ctx.train_begin(1e-3)
+    rgb, gc, gf = ctx.train_render_gradients(o, d, d_rgb, sc, sf, u_c, u_f)
+    r = T.render_gradients(bc, bf, o, d, d_rgb, near, far, u_c, u_f, alpha=1.0, **kw)
+    ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
+    assert np.abs(rgb - r["rgb"]).max() <= 5e-5
+    ctx.close()
+    ctx = N.Context(near=near, far=far, n_angles=n_angles, leaky_relu_alpha=1.0)
+    ctx.load_weights(0, bc)
+    ctx.load_weights(1, bf)
+    ctx.train_begin(1e-3, mixed_float16=True)
+    m, hc, hf = ctx.train_gradients(o, d, tgt, sc, sf, u_c, u_f)
+    r16 = T.train_gradients(bc, bf, o, d, tgt, near, far, u_c, u_f, alpha=1.0, fp16_loss_scale=32768.0, **kw)
+    qc, qf = _relerr(hc, r16["grad_coarse"]), _relerr(hf, r16["grad_fine"])
+    ctx.close()
+    with capsys.disabled():
+        print(f"\n[n_angles {n_angles}] backward through render() vs float64: coarse {ec:.2e}, fine {ef:.2e}; mixed_float16 "
+              f"train_step gradients vs the fp16-emulating oracle: coarse {qc:.2e}, fine {qf:.2e}", end="")
+    assert ec <= 2e-4 and ef <= 2e-4
+    # (the coarse gradient runs through the sampler's gains: measured 1.2e-2 on this problem, 8.6e-4 on the one above)
+    assert abs(m["loss"] - r16["loss"]) <= 1e-4 * r16["loss"] and qc <= 3e-2 and qf <= 5e-3
+
+
+def test_abi3_entry_points_fail_loudly(oracle, golden_ckpt):
+    """nerf_host_alloc / nerf_host_free / nerf_train_get_gradients: argument errors are statuses + messages, never aborts."""
+    import ctypes as C
+    import nerf_and_dietnerf_amd as N
+    lib = N._lib.load()
+    out = C.c_void_p()
+    assert lib.nerf_host_alloc(0, C.byref(out)) != 0 and "0 bytes" in N._lib.last_error()
+    assert lib.nerf_host_alloc(4096, None) != 0
+    assert lib.nerf_host_alloc(1 << 20, C.byref(out)) == 0 and out.value
+    buf = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_float)), shape=(1 << 18,))
+    buf[:] = 3.0                                        # ordinary host memory to the CPU
+    assert float(buf.sum()) == 3.0 * (1 << 18)
+    assert lib.nerf_host_free(out) == 0 and lib.nerf_host_free(None) == 0
+    p = _problem(oracle, golden_ckpt, n=8, sc=4, sf=4)
+    ctx = _ctx(p)
+    g = np.empty(ctx.blob_size(), np.float32)
+    assert lib.nerf_train_get_gradients(ctx.h, 0, g.ctypes.data, g.size, 0) != 0          # no trainer yet
+    assert "nerf_train_begin" in N._lib.last_error()
+    ctx.train_begin(5e-4)
+    assert lib.nerf_train_get_gradients(ctx.h, 0, g.ctypes.data, g.size - 1, 0) != 0
+    assert lib.nerf_train_get_gradients(ctx.h, 2, g.ctypes.data, g.size, 0) != 0
+    _, gc, _ = ctx.train_gradients(p["o"], p["d"], p["tgt"], p["sc"], p["sf"], p["u_c"], p["u_f"])
+    np.testing.assert_array_equal(ctx.train_get_gradients(0), gc)
+    ctx.close()
