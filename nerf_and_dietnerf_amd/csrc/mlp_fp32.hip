@@ -30,6 +30,24 @@ namespace nerf {
 __device__ unsigned long long g_stamps[16];
 #endif
 
+// The xyz-only network (get_network_only_xyz, src/NeRF.py:248-288: 12 Dense layers, sigma = Dense(1)(h8), the colour
+// branch h8 -> 256 -> 128 -> rgb) on the same skeleton: two more body kinds and its own constant layout.
+//   BODY_HSIG  : BODY_HID for the extra 256-wide layer; while its second tile pair runs -- h8 is complete in xin from the
+//                end of the first pair (the pending tiles 6, 7) until the last pair's copy-back -- the 256 -> 1 sigma head
+//                is accumulated on the VALU, one weight quad per k-quad (the view-direction network does it after layer 8,
+//                when xin still holds h8; here layer 8 overwrites it)
+//   BODY_LASTX : BODY_LAST without the direction rows (256 -> 128)
+enum { BODY_HSIG = 6, BODY_LASTX = 7 };
+constexpr int kFXConstBias8 = 2048;      // 256: the extra layer (contiguous with layers 0..7: the bias preload runs ahead)
+constexpr int kFXConstBias9 = 2304;      // 128
+constexpr int kFXConstWrgb = 2432;       // [3][128]
+constexpr int kFXConstBHead = 2816;      // b_r, b_g, b_b, b_sigma
+constexpr int kFXConstWsigH = 2820;      // [256]
+static_assert(kFXConstWsigH + 256 <= kConstFloats, "xyz-only fp32 constants must fit the LDS carve");
+constexpr int kChunksLastX = (4 * kQpuHid) / 16;                                                        // 8
+constexpr int kStreamChunksXyz = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksHid + kChunksLastX;   // 142
+static_assert((size_t)kStreamChunksXyz * kChunkBytes == kStreamBytesXyzF32, "xyz-only fp32 stream size mismatch");
+
 // One dense layer, u-outer: for each 32-wide output tile run the whole K chain into one accumulator.
 //   BODY_PE   : B = xpe                      -> xin   (layer 0)
 //   BODY_HID  : B = xin                      -> xin   (layers 1-3, 5-7; via xnext + staged copy-back)
@@ -39,12 +57,14 @@ template <int BODY, bool PENDING>
 __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
                                            uint32_t cb_h, int bias_off_bytes, float alpha, f32x16 (&accs)[4],
                                            float (&xin)[128], float (&xnext)[96], const float (&xpe)[17],
-                                           const float (&xdir)[12], float (&xc)[64]) {
+                                           const float (&xdir)[12], float (&xc)[64], float& sig) {
+    constexpr bool kHid = BODY == BODY_HID || BODY == BODY_HSIG;
+    constexpr bool kLast = BODY == BODY_LAST || BODY == BODY_LASTX;
     // Output tiles are processed in PAIRS (u = 2P, 2P+1): the two accumulator chains alternate MFMA by
     // MFMA, so a dependent v_mfma_f32_32x32x2_f32 is never issued back to back on one accumulator,
     // and both chains share every B operand.  Stream order per pair: quad(2P,q), quad(2P+1,q), q++.
-    constexpr int NP = BODY == BODY_LAST ? 2 : 4;
-    constexpr int QPU = BODY == BODY_PE ? kQpuPE : BODY == BODY_HID ? kQpuHid
+    constexpr int NP = kLast ? 2 : 4;
+    constexpr int QPU = BODY == BODY_PE ? kQpuPE : (kHid || BODY == BODY_LASTX) ? kQpuHid
                         : BODY == BODY_SKIP ? kQpuSkip : kQpuLast;
     constexpr int NQ = NP * 2 * QPU;
     // accs[0..1]: pair accumulators of even pairs, accs[2..3]: of odd pairs.  They live across layers:
@@ -82,7 +102,7 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
     auto dest_of = [](auto uc) {
         constexpr int u = decltype(uc)::value;
         if constexpr (BODY == BODY_PE) return std::integral_constant<int, 0>{};
-        else if constexpr (BODY == BODY_LAST) return std::integral_constant<int, 2>{};
+        else if constexpr (kLast) return std::integral_constant<int, 2>{};
         else if constexpr (u >= 6) return std::integral_constant<int, 0>{};
         else return std::integral_constant<int, 1>{};
     };
@@ -135,7 +155,7 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
                 float b = 0.f;
                 if constexpr (BODY == BODY_PE) {
                     if constexpr (s < 17) b = xpe[s]; else live = false;
-                } else if constexpr (BODY == BODY_HID) {
+                } else if constexpr (kHid || BODY == BODY_LASTX) {
                     b = xin[s];
                 } else if constexpr (BODY == BODY_SKIP) {
                     if constexpr (q < kQpuPE) { if constexpr (s < 17) b = xpe[s]; else live = false; }
@@ -148,6 +168,12 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][e], b, acc1, 0, 0, 0);
                 }
             });
+            if constexpr (BODY == BODY_HSIG && P == 1) {
+                // sigma head of the xyz-only network on h8 (= xin, complete during this pair): features of k-quad q
+                const f32x4 w = lds_read4(cb_h + (kFXConstWsigH + (q >> 2) * 32 + (q & 3) * 8) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sig = fmaf(w[e], xin[(q >> 2) * 16 + (q & 3) * 4 + e], sig);
+            }
             // Deferred epilogue of the previous pair, spread over this pair's MFMA gaps: the VALU work
             // hides only while each 64-cycle MFMA gap carries a few instructions, so it is dealt out
             // kEpi elements per quad-pair (8 MFMAs) instead of in one block.
@@ -173,11 +199,11 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
             // contiguous in the constant region -- so that no chain starts on an LDS round trip
             if constexpr (q == (QPU >= 20 ? 18 : QPU - 1)) {
                 if constexpr (P + 1 < NP) load_bias_pair(bias_off_bytes + (P + 1) * 256, prv0, prv1);
-                else if constexpr (BODY != BODY_LAST) load_bias_pair(bias_off_bytes + 1024, prv0, prv1);
+                else if constexpr (!kLast) load_bias_pair(bias_off_bytes + 1024, prv0, prv1);
             }
             // last pair of an in-place layer: tile t of xin is dead once its 4 quads (4t..4t+3) are
             // consumed; copy xnext back 4 registers per quad over the following 4 quads
-            if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && P == NP - 1) {
+            if constexpr ((kHid || BODY == BODY_SKIP) && P == NP - 1) {
                 constexpr int qh = BODY == BODY_SKIP ? q - kQpuPE : q;
                 if constexpr (qh >= 4 && qh < 28) {
                     constexpr int t = (qh - 4) >> 2;
@@ -190,7 +216,7 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
             }
         });
     });
-    if constexpr (BODY == BODY_LAST) {   // layer 8 feeds the heads right away: finish its last pair here
+    if constexpr (kLast) {   // the last layer feeds the heads right away: finish its last pair here
         f32x16& l0 = accs[((NP - 1) & 1) * 2 + 0];
         f32x16& l1 = accs[((NP - 1) & 1) * 2 + 1];
         static_for<0, 8>([&](auto rc) {
@@ -203,7 +229,8 @@ __device__ __forceinline__ void layer_body(Pipe& p, uint32_t lane16,
     p.ck += 1;  // every body starts on a chunk boundary
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
+template <bool XYZ>
+__device__ __forceinline__ void mlp_fp32_body(const MlpArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = kStreamChunks;
+    p.n_chunks = XYZ ? kStreamChunksXyz : kStreamChunks;
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (4 * kQuadBytes);
@@ -266,7 +293,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
             dx = d[0]; dy = d[1]; dz = d[2];
         } else {
             px = a.in_a[mm * 3 + 0]; py = a.in_a[mm * 3 + 1]; pz = a.in_a[mm * 3 + 2];
-            dx = a.in_b[mm * 3 + 0]; dy = a.in_b[mm * 3 + 1]; dz = a.in_b[mm * 3 + 2];
+            if constexpr (XYZ) { dx = dy = dz = 0.f; }        // no view directions in this network (in_b may be null)
+            else { dx = a.in_b[mm * 3 + 0]; dy = a.in_b[mm * 3 + 1]; dz = a.in_b[mm * 3 + 2]; }
         }
         const float kPi = 3.1415927410125732f;   // fp32(pi): theta = (2^k * pi_f32) * x
 #pragma unroll
@@ -286,19 +314,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
 
         // ---------------- the 9 MFMA layers ----------------
         STAMP(t1); acc_t[0] += t1 - t0;
-        layer_body<BODY_PE, false>(p, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
+        float sig = 0.f;
+        layer_body<BODY_PE, false>(p, lane16, cb_h, (kConstBias + 0 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
         STAMP(t0); acc_t[1] += t0 - t1;
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             if (l == 4) {
-                layer_body<BODY_SKIP, true>(p, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
+                layer_body<BODY_SKIP, true>(p, lane16, cb_h, (kConstBias + 4 * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
                 STAMP(t1); acc_t[3] += t1 - t0; t0 = t1;
             } else {
-                layer_body<BODY_HID, true>(p, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
+                layer_body<BODY_HID, true>(p, lane16, cb_h, (kConstBias + l * 256) * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
                 STAMP(t1); acc_t[2] += t1 - t0; t0 = t1;
             }
         }
-        layer_body<BODY_LAST, true>(p, lane16, cb_h, kConstBias8 * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc);
+        if constexpr (XYZ) {
+            layer_body<BODY_HSIG, true>(p, lane16, cb_h, kFXConstBias8 * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
+            layer_body<BODY_LASTX, true>(p, lane16, cb_h, kFXConstBias9 * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
+        } else {
+            layer_body<BODY_LAST, true>(p, lane16, cb_h, kConstBias8 * 4, a.alpha, accs, xin, xnext, xpe, xdir, xc, sig);
+        }
         STAMP(t1); acc_t[4] += t1 - t0;
 
         // ---------------- heads on the VALU ----------------
@@ -307,9 +341,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 w0 = lds_read4(cb_h + (kConstWrgb + 0 * 128 + t * 32 + g * 8) * 4);
-                const f32x4 w1 = lds_read4(cb_h + (kConstWrgb + 1 * 128 + t * 32 + g * 8) * 4);
-                const f32x4 w2 = lds_read4(cb_h + (kConstWrgb + 2 * 128 + t * 32 + g * 8) * 4);
+                constexpr int kW = XYZ ? kFXConstWrgb : kConstWrgb;
+                const f32x4 w0 = lds_read4(cb_h + (kW + 0 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w1 = lds_read4(cb_h + (kW + 1 * 128 + t * 32 + g * 8) * 4);
+                const f32x4 w2 = lds_read4(cb_h + (kW + 2 * 128 + t * 32 + g * 8) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = xc[t * 16 + g * 4 + e];
@@ -319,26 +354,30 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
                 }
             }
         }
+        if constexpr (XYZ) {
+            o3 = sig;                         // accumulated beside the extra layer's MFMAs (BODY_HSIG)
+        } else {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 8; ++t) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 w = lds_read4(cb_h + (kConstWsigH + t * 32 + g * 8) * 4);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w = lds_read4(cb_h + (kConstWsigH + t * 32 + g * 8) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o3 = fmaf(w[e], xin[t * 16 + g * 4 + e], o3);
+                    for (int e = 0; e < 4; ++e) o3 = fmaf(w[e], xin[t * 16 + g * 4 + e], o3);
+                }
             }
-        }
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const f32x4 w = lds_read4(cb_h + (kConstWsigD + g * 8) * 4);
+            for (int g = 0; g < 3; ++g) {
+                const f32x4 w = lds_read4(cb_h + (kConstWsigD + g * 8) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o3 = fmaf(w[e], xdir[g * 4 + e], o3);
+                for (int e = 0; e < 4; ++e) o3 = fmaf(w[e], xdir[g * 4 + e], o3);
+            }
         }
         o0 += __shfl_xor(o0, 32);
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
         o3 += __shfl_xor(o3, 32);
-        const f32x4 bh = lds_read4(kLdsConst + kConstBHead * 4);
+        const f32x4 bh = lds_read4(kLdsConst + (XYZ ? kFXConstBHead : kConstBHead) * 4);
         if (valid && h == 0) {
             f32x4 out;
             out[0] = o0 + bh[0]; out[1] = o1 + bh[1]; out[2] = o2 + bh[2]; out[3] = o3 + bh[3];
@@ -357,11 +396,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream) {
+__global__ __launch_bounds__(256, 1) void mlp_fp32_kernel(const MlpArgs a) { mlp_fp32_body<false>(a); }
+__global__ __launch_bounds__(256, 1) void mlp_fp32_xyz_kernel(const MlpArgs a) { mlp_fp32_body<true>(a); }
+
+void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream, bool xyz_only) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 127) / 128;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    if (xyz_only) hipLaunchKernelGGL(mlp_fp32_xyz_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    else hipLaunchKernelGGL(mlp_fp32_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
 }
 
 #ifdef NERF_STAMPS
@@ -373,6 +416,8 @@ extern "C" void nerf_debug_read_stamps(unsigned long long* out) {
 
 void mlp_fp32_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fp32_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fp32_xyz_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
 }
 
@@ -403,21 +448,27 @@ struct Layer { const float* k; const float* b; int in, out; };
 
 void pack_weights_fp32(const float* blob, int n_angles, float* stream_out, float* const_out) {
     const int kd = 256 + 8 * (n_angles + 1);   // width of [hidden, dir_enc]: 280 (n_angles 2) or 272 (1)
-    const int shapes[11][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
-                               {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}};
-    Layer L[11];
+    const bool xyz_only = n_angles == 0;
+    const int shapes_dir[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {kd, 128}, {128, 3}, {kd, 1}, {0, 0}};
+    // get_network_only_xyz (src/NeRF.py:248-288): ..., 8: 256 -> 256, 9: 256 -> 128, 10: 128 -> 3, 11: 256 -> 1
+    const int shapes_xyz[12][2] = {{33, 256}, {256, 256}, {256, 256}, {256, 256}, {289, 256}, {256, 256},
+                                   {256, 256}, {256, 256}, {256, 256}, {256, 128}, {128, 3}, {256, 1}};
+    const int (*shapes)[2] = xyz_only ? shapes_xyz : shapes_dir;
+    Layer L[12];
     size_t off = 0;
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < (xyz_only ? 12 : 11); ++i) {
         L[i].in = shapes[i][0]; L[i].out = shapes[i][1];
         L[i].k = blob + off; off += (size_t)L[i].in * L[i].out;
         L[i].b = blob + off; off += L[i].out;
     }
-    memset(stream_out, 0, kStreamBytes);
+    memset(stream_out, 0, xyz_only ? kStreamBytesXyzF32 : kStreamBytes);
     memset(const_out, 0, kConstBytes);
     size_t chunk = 0;
     auto emit_body = [&](int layer, int body) {
-        const int NU = body == BODY_LAST ? 4 : 8;
-        const int QPU = body == BODY_PE ? kQpuPE : body == BODY_HID ? kQpuHid : body == BODY_SKIP ? kQpuSkip : kQpuLast;
+        const int NU = (body == BODY_LAST || body == BODY_LASTX) ? 4 : 8;
+        const int QPU = body == BODY_PE ? kQpuPE : (body == BODY_HID || body == BODY_LASTX) ? kQpuHid
+                        : body == BODY_SKIP ? kQpuSkip : kQpuLast;
         float* base = stream_out + chunk * (kChunkBytes / 4);
         for (int u = 0; u < NU; ++u)
             for (int q = 0; q < QPU; ++q) {
@@ -428,7 +479,7 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out, float
                         const int i = lane & 31, h = lane >> 5;
                         int row;
                         if (body == BODY_PE) row = pe_row(4 * q + e, h);
-                        else if (body == BODY_HID) row = hid_row(4 * q + e, h);
+                        else if (body == BODY_HID || body == BODY_LASTX) row = hid_row(4 * q + e, h);
                         else if (body == BODY_SKIP) row = q < kQpuPE ? pe_row(4 * q + e, h) : kXyzDim + hid_row(4 * (q - kQpuPE) + e, h);
                         else if (q < kQpuHid) row = hid_row(4 * q + e, h);
                         else { const int r = dir_row(4 * (q - kQpuHid) + e, h, n_angles); row = r < 0 ? -1 : kHidden + r; }
@@ -441,10 +492,22 @@ void pack_weights_fp32(const float* blob, int n_angles, float* stream_out, float
     for (int l = 1; l <= 3; ++l) emit_body(l, BODY_HID);
     emit_body(4, BODY_SKIP);
     for (int l = 5; l <= 7; ++l) emit_body(l, BODY_HID);
-    emit_body(8, BODY_LAST);
-    // constants
     for (int l = 0; l < 8; ++l)
         for (int f = 0; f < 256; ++f) const_out[kConstBias + l * 256 + f] = L[l].b[f];
+    if (xyz_only) {
+        emit_body(8, BODY_HID);          // the kernel runs it as BODY_HSIG: same operand order
+        emit_body(9, BODY_LASTX);
+        for (int f = 0; f < 256; ++f) const_out[kFXConstBias8 + f] = L[8].b[f];
+        for (int f = 0; f < 128; ++f) const_out[kFXConstBias9 + f] = L[9].b[f];
+        for (int c = 0; c < 3; ++c)
+            for (int f = 0; f < 128; ++f) const_out[kFXConstWrgb + c * 128 + f] = L[10].k[f * 3 + c];
+        for (int c = 0; c < 3; ++c) const_out[kFXConstBHead + c] = L[10].b[c];
+        const_out[kFXConstBHead + 3] = L[11].b[0];
+        for (int f = 0; f < 256; ++f) const_out[kFXConstWsigH + f] = L[11].k[f];
+        return;
+    }
+    emit_body(8, BODY_LAST);
+    // constants
     for (int f = 0; f < 128; ++f) const_out[kConstBias8 + f] = L[8].b[f];
     for (int c = 0; c < 3; ++c)
         for (int f = 0; f < 128; ++f) const_out[kConstWrgb + c * 128 + f] = L[9].k[f * 3 + c];

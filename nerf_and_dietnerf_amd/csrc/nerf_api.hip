@@ -61,16 +61,21 @@ int upload_packed_weights(nerf_ctx* c, int which, const float* blob) {
     HIP_OK(hipSetDevice(c->cfg.device));
     NetWeights& n = c->net[which];
     if (c->cfg.n_angles == 0) {
-        // xyz-only network: the exact-fp32 mode is served by the layer-wise path (train_api.hip: nothing to pack for it);
-        // the two fp16-core modes run on the fused kernels' xyz-only variant with their own streams
+        // xyz-only network: all three arithmetic modes run on the fused kernels' xyz-only variants, each with its own
+        // stream and constant layout
         std::vector<uint16_t> sx(kStreamBytesF16Xyz / 2), sx1(kStreamBytesF16HiXyz / 2);
-        std::vector<float> cx(kConstFloats);
+        std::vector<float> cx(kConstFloats), sf(kStreamBytesXyzF32 / 4), cf(kConstFloats);
         pack_weights_f16x3(blob, 0, sx.data(), cx.data());
         pack_weights_f16(blob, 0, sx1.data(), cx.data());
+        pack_weights_fp32(blob, 0, sf.data(), cf.data());
         if (!n.stream_h) HIP_OK(hipMalloc((void**)&n.stream_h, kStreamBytesF16Xyz));
         if (!n.stream_h1) HIP_OK(hipMalloc((void**)&n.stream_h1, kStreamBytesF16HiXyz));
         if (!n.cst_h) HIP_OK(hipMalloc((void**)&n.cst_h, kConstBytes));
+        if (!n.stream) HIP_OK(hipMalloc((void**)&n.stream, kStreamBytesXyzF32));
+        if (!n.cst) HIP_OK(hipMalloc((void**)&n.cst, kConstBytes));
         HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipMemcpy(n.stream, sf.data(), kStreamBytesXyzF32, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(n.cst, cf.data(), kConstBytes, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(n.stream_h, sx.data(), kStreamBytesF16Xyz, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(n.stream_h1, sx1.data(), kStreamBytesF16HiXyz, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(n.cst_h, cx.data(), kConstBytes, hipMemcpyHostToDevice));
@@ -128,11 +133,6 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
             int S, int mode) {
     if (!c->net[which].loaded) return fail("network %d has no weights loaded", which);
     if (int r = train_flush_weights(c, which)) return r;   // re-pack the operand streams after optimizer steps
-    if (c->cfg.n_angles == 0 && c->cfg.precision == NERF_PRECISION_FP32) {
-        if (mode == 1 && !in_a) return fail("NULL argument");
-        c->timed_rows += c->timing ? M : 0;
-        return layerwise_forward(c, which, in_a, in_b, z, raw, M, S, mode);
-    }
     const bool f16 = c->cfg.precision == NERF_PRECISION_F16X3 || c->cfg.precision == NERF_PRECISION_F16;
     MlpArgs a{};
     a.wstream = c->cfg.precision == NERF_PRECISION_F16 ? (const float*)c->net[which].stream_h1
@@ -159,7 +159,7 @@ int run_mlp(nerf_ctx* c, int which, const float* in_a, const float* in_b, const 
     static const bool one_tile = [] { const char* e = getenv("NERF_F16_TILES"); return e && e[0] == '1'; }();
     if (c->cfg.precision == NERF_PRECISION_F16 && c->cfg.n_angles != 0 && !one_tile) launch_mlp_f16_2t(a, c->num_cus, c->stream);
     else if (f16) launch_mlp_f16x3(a, c->num_cus, c->stream, c->cfg.precision == NERF_PRECISION_F16, c->cfg.n_angles == 0);
-    else launch_mlp_fp32(a, c->num_cus, c->stream);
+    else launch_mlp_fp32(a, c->num_cus, c->stream, c->cfg.n_angles == 0);
     if (c->timing) HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipGetLastError());
     return 0;

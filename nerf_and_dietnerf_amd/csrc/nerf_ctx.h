@@ -75,7 +75,6 @@ int comm_world(const nerf_ctx* c);                            // ranks of the ct
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob_host);   // nerf_api.hip: pack + upload streams
 int train_on_load(nerf_ctx* c, int which);          // train_api.hip: no-op without a trainer
 int train_flush_weights(nerf_ctx* c, int which);
-int layerwise_forward(nerf_ctx* c, int which, const float* in_a, const float* in_b, const float* z, float* raw,
-                      long long M, int S, int mode);   // train_api.hip: MLP of the xyz-only network (n_angles = 0)    // train_api.hip: no-op unless optimizer steps changed the weights
+// (train_flush_weights: train_api.hip, no-op unless optimizer steps changed the weights)
 
 }  // namespace nerf

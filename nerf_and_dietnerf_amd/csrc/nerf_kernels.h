@@ -36,6 +36,7 @@ constexpr int kChunksSkip = (8 * kQpuSkip + 15) / 16;  // 19
 constexpr int kChunksLast = (4 * kQpuLast + 15) / 16;  // 9
 constexpr int kStreamChunks = kChunksPE + 3 * kChunksHid + kChunksSkip + 3 * kChunksHid + kChunksLast;  // 127
 constexpr size_t kStreamBytes = size_t(kStreamChunks) * kChunkBytes;
+constexpr size_t kStreamBytesXyzF32 = size_t(142) * kChunkBytes;   // the xyz-only network's fp32 stream (12 Dense layers, mlp_fp32.hip)
 constexpr size_t kStreamBytesF16 = size_t(66) * 32 * kQuadBytes;   // f16x3 stream: 66 chunks of 32 KiB (mlp_f16x3.hip)
 constexpr size_t kStreamBytesF16Hi = size_t(33) * 32 * kQuadBytes; // single-pass fp16 stream: hi fragments only
 constexpr size_t kStreamBytesF16Xyz = size_t(73) * 32 * kQuadBytes;    // the xyz-only network's streams (12 Dense layers)
@@ -79,10 +80,10 @@ struct MlpArgs {
 };
 
 // mlp_fp32.hip
-void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream);
+void launch_mlp_fp32(const MlpArgs& a, int num_cus, hipStream_t stream, bool xyz_only = false);
 void mlp_fp32_set_attributes();
 // host-side packing of one network's blob (11 x (kernel(in,out), bias)) into stream + const
-void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStreamBytes/4*/, float* const_out /*kConstFloats*/);
+void pack_weights_fp32(const float* blob, int n_angles, float* stream_out /*kStreamBytes/4; n_angles 0: kStreamBytesXyzF32/4*/, float* const_out /*kConstFloats*/);
 
 // mlp_f16x3.hip
 // single_pass: hi*hi only; xyz_only: the 12-layer network without view directions (its own streams / constants)

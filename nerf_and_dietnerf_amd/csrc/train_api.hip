@@ -28,7 +28,6 @@ struct TLayer {
 struct TNet {
     bool present = false;
     bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
-    bool mats_dirty = false;       // ... nor into the padded matrices of the layer-wise path (fused trainer skips them)
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
     void* fstream = nullptr;       // fused forward (f16x3 stash kernel): operand stream + constants, re-packed on device
     float* fcst = nullptr;
@@ -47,7 +46,7 @@ struct TPass {                      // activations of one pass, kept from forwar
 
 struct TrainState {
     nerf_train_config cfg;
-    bool training = false;          // false: created only to serve the layer-wise forward of the xyz-only network
+    bool training = false;          // set by nerf_train_begin
     bool fused_forward = false;     // forward pass on the fused split-fp16 kernel with activation stash (n_angles > 0)
     int32_t *sidx = nullptr, *cidx = nullptr;   // device gather tables of the fused kernel's stream / constants
     bool fused_backward = false;    // data gradients by the fused chain kernel (needs the fused forward's mask records)
@@ -70,7 +69,6 @@ struct TrainState {
     bool mixed = false;
     DevBuf opt;                     // OptState (train_kernels.h): loss scale, verdicts, Adam iteration count -- on the device
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
-    TPass infer;                    // chunk-sized activations of the layer-wise forward (render path, xyz-only network)
 };
 
 }  // namespace nerf
@@ -103,16 +101,14 @@ int layer_table(const nerf_config& cfg, TLayer L[12]) {
 
 void free_buf(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
-int relayout_net(nerf_ctx* c, TNet& n, bool force_mats = false) {
+int relayout_net(nerf_ctx* c, TNet& n) {
     if (n.fstream)
         launch_repack_f16x3(n.blob, c->train->sidx, n.fstream, c->train->cidx, n.fcst,
                             f16_stream_bytes(c->cfg.n_angles, c->train->mixed), c->stream);
     if (n.bstream) launch_repack_bwd(n.blob, c->train->bidx[n.bdx ? 1 : 0], n.bstream, c->stream);
-    // the padded W / W^T / hi-lo planes feed the layer-wise GEMMs only; the fused forward + backward read the two
-    // re-packed streams above and nothing else (22 launches per step that nobody read).  The xyz-only network's exact-fp32
-    // render mode does read them (layerwise_forward): they are brought up to date there, on demand.
-    if (c->train->training && c->train->frag && !force_mats) { n.mats_dirty = true; HIP_OK(hipGetLastError()); return 0; }
-    n.mats_dirty = false;
+    // the padded W / W^T / hi-lo planes feed the layer-wise GEMMs only (NERF_TRAIN_* switches); the fused forward + backward
+    // read the two re-packed streams above and nothing else (22 launches per step that nobody read)
+    if (c->train->frag) { HIP_OK(hipGetLastError()); return 0; }
     for (int l = 0; l < n.n_layers; ++l) {
         const TLayer& L = n.L[l];
         RelayoutArgs a;
@@ -758,7 +754,7 @@ void train_free(nerf_ctx* c) {
     if (t->sidx) (void)hipFree(t->sidx);
     if (t->cidx) (void)hipFree(t->cidx);
     for (int32_t* bi : t->bidx) if (bi) (void)hipFree(bi);
-    TPass* passes[] = {&t->pass[0], &t->pass[1], &t->infer};
+    TPass* passes[] = {&t->pass[0], &t->pass[1]};
     for (TPass* pp : passes) {
         TPass& p = *pp;
         DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
@@ -776,13 +772,6 @@ void train_free(nerf_ctx* c) {
 
 int train_on_load(nerf_ctx* c, int which) {
     TrainState* t = c->train;
-    if (!t && c->cfg.n_angles == 0) {
-        // the xyz-only network renders through the layer-wise GEMM path: keep its padded matrices resident
-        t = new TrainState();
-        t->training = false;
-        t->nblob = nerf_blob_size(&c->cfg);
-        c->train = t;
-    }
     if (!t) return 0;
     TNet& n = t->net[which];
     if (!n.present) return init_net(c, t, which);
@@ -792,40 +781,9 @@ int train_on_load(nerf_ctx* c, int which) {
     return relayout_net(c, n);
 }
 
-// Render-path MLP for the xyz-only network (no fused kernel is built for it): encode + Dense stack layer by
-// layer on the fp32 MFMA GEMMs, in chunks of 128 Ki sample rows (1.2 GB of activations per chunk).
-int layerwise_forward(nerf_ctx* c, int which, const float* in_a, const float* in_b, const float* z, float* raw,
-                      long long M, int S, int mode) {
-    TrainState* t = c->train;
-    if (!t || !t->net[which].present) return fail("network %d has no weights loaded", which);
-    if (t->net[which].mats_dirty)          // the fused trainer does not keep the padded matrices current
-        if (int r = relayout_net(c, t->net[which], true)) return r;
-    constexpr long long kChunk = 1 << 17;
-    const long long cap = M < kChunk ? (M + 127) / 128 * 128 : kChunk;
-    PassDims d{0, S, cap, cap};
-    TPass& p = t->infer;
-    if (int r = ensure_pass(c, p, d)) return r;
-    for (long long row0 = 0; row0 < M; row0 += kChunk) {
-        const long long rows = M - row0 < kChunk ? M - row0 : kChunk;
-        const long long Mp = (rows + 127) / 128 * 128;
-        launch_train_encode(in_a, in_b, z, row0, rows, S, Mp, c->cfg.n_angles, mode, (float*)p.C4.p, (float*)p.C8.p,
-                            c->stream);
-        if (Mp == rows) {
-            forward_layers(c, t->net[which], p, Mp, raw + row0 * 4);
-        } else {   // the padded tail rows must not be written past the caller's (M,4) buffer
-            forward_layers(c, t->net[which], p, Mp, (float*)p.raw.p);
-            HIP_OK(hipMemcpyAsync(raw + row0 * 4, p.raw.p, rows * 4 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        }
-    }
-    HIP_OK(hipGetLastError());
-    return 0;
-}
-
 int train_flush_weights(nerf_ctx* c, int which) {
     TrainState* t = c->train;
     if (!t || !t->net[which].present || !t->net[which].render_dirty) return 0;
-    // (the xyz-only network's exact-fp32 render mode reads the trainer's own matrices, its fp16-core modes the streams
-    // re-packed here like everyone else's)
     NetWeights& nw = c->net[which];
     HIP_OK(hipMemcpyAsync(nw.host_blob.data(), t->net[which].blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost,
                           c->stream));
@@ -909,15 +867,6 @@ int nerf_train_end(nerf_ctx* c) {
     for (int w = 0; w < 2; ++w)
         if (int r = train_flush_weights(c, w)) return r;
     HIP_OK(hipStreamSynchronize(c->stream));
-    if (c->cfg.n_angles == 0 && c->train) {
-        // the render path of the xyz-only network keeps using the (now trained) matrices; sync the host copy
-        for (int w = 0; w < 2; ++w)
-            if (c->train->net[w].present)
-                HIP_OK(hipMemcpy(c->net[w].host_blob.data(), c->train->net[w].blob, c->train->nblob * sizeof(float),
-                                 hipMemcpyDeviceToHost));
-        c->train->training = false;
-        return 0;
-    }
     train_free(c);
     return 0;
 }

@@ -700,31 +700,36 @@ def test_xyz_only_network(oracle, precision):
 
 
 def test_xyz_only_network_rate(capsys):
-    """The fused xyz-only variant must not be a second-class path: >= 0.8 of the view-direction network's rate at
-    256x256, 64 + 128 (it does 262144 more MACs per sample row: one 256x256 layer instead of the 24 direction rows)."""
+    """The fused xyz-only variants must not be a second-class path: >= 0.8 of the view-direction network's rate at
+    256x256, 64 + 128 (it does 262144 more MACs per sample row: one 256x256 layer instead of the 24 direction rows) -- in
+    the f16x3 mode and, since round 3, in the exact-fp32 mode too (mlp_fp32_xyz_kernel; layer by layer on GEMMs before)."""
     import time
     import torch
     import nerf_and_dietnerf_amd as N
     rates = {}
-    for n_angles in (2, 0):
-        ctx = N.Context(n_angles=n_angles, near=0.5, far=2.5, precision="f16x3")
-        ctx.load_weights(0, N.glorot_blob(1, n_angles=n_angles))
-        ctx.load_weights(1, N.glorot_blob(2, n_angles=n_angles))
-        c2w = np.eye(4, dtype=np.float32)
-        c2w[2, 3] = 1.5
-        f = lambda s: ctx.render_image(c2w, 0.6, 256, 256, 1 << 18, 64, 128, seed=s, device_out=True, rgb_only=True)  # noqa: E731
-        f(0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(5):
-            f(s + 1)
-        torch.cuda.synchronize()
-        rates[n_angles] = 5 * 65536 / (time.perf_counter() - t0)
-        ctx.close()
+    for precision in ("f16x3", "fp32"):
+        for n_angles in (2, 0):
+            ctx = N.Context(n_angles=n_angles, near=0.5, far=2.5, precision=precision)
+            ctx.load_weights(0, N.glorot_blob(1, n_angles=n_angles))
+            ctx.load_weights(1, N.glorot_blob(2, n_angles=n_angles))
+            c2w = np.eye(4, dtype=np.float32)
+            c2w[2, 3] = 1.5
+            f = lambda s: ctx.render_image(c2w, 0.6, 256, 256, 1 << 18, 64, 128, seed=s, device_out=True, rgb_only=True)  # noqa: E731
+            f(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = 5 if precision == "f16x3" else 3
+            for s in range(k):
+                f(s + 1)
+            torch.cuda.synchronize()
+            rates[(precision, n_angles)] = k * 65536 / (time.perf_counter() - t0)
+            ctx.close()
     with capsys.disabled():
-        print(f"\n[xyz-only fused kernel] {rates[0]:.3e} rays/s vs {rates[2]:.3e} rays/s with view directions "
-              f"(ratio {rates[0] / rates[2]:.2f})")
-    assert rates[0] >= 0.8 * rates[2]
+        for precision in ("f16x3", "fp32"):
+            print(f"\n[xyz-only fused kernel, {precision}] {rates[(precision, 0)]:.3e} rays/s vs {rates[(precision, 2)]:.3e} rays/s "
+                  f"with view directions (ratio {rates[(precision, 0)] / rates[(precision, 2)]:.2f})", end="")
+    assert rates[("f16x3", 0)] >= 0.8 * rates[("f16x3", 2)]
+    assert rates[("fp32", 0)] >= 0.8 * rates[("fp32", 2)]
 
 
 def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):
