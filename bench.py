@@ -408,11 +408,11 @@ def main():
         rows_tr = n_tr * (SC + SF)
         elems_per_row = 7 * 256 + 320 + 288 + 128 + 8 * 256 + 128      # stash (incl. the two concat buffers) + D buffers
 
-        def hbm_view(ms, key, elem_bytes):
+        def hbm_view(seconds, key, elem_bytes):
             by = tr_bytes.get(key)
             algo = rows_tr * elems_per_row * elem_bytes * 2.0
-            return {"bound": "hbm", "achieved": (by / (ms * 1e-3) / 1e9) if by else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": (by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if by else None, "traffic": by,
+            return {"bound": "hbm", "achieved": (by / seconds / 1e9) if by else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": (by / seconds / 1e9 / PEAK_HBM_GBS) if by else None, "traffic": by,
                     "traffic_source": "offline rocprofv3 PMC, summed over the kernels of one step (profiles/pmc_traffic.json)",
                     "structural_bytes": algo, "traffic_vs_structural": (by / algo) if by else None,
                     "note": "the step is HBM-bound: activations and pre-activation gradients are written once (stash "
