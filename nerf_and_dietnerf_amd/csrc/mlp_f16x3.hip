@@ -119,7 +119,11 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         else {
             f32x4 v;
             v[0] = sq0; v[1] = sq1; v[2] = y0; v[3] = y1;
+#ifndef NERF_DIAG_NO_STASH_STORES   // timing-only diagnostic: everything but the store instruction itself
             *reinterpret_cast<f32x4*>(base + 32 * (32 * ut + 8 * (r >> 2))) = v;
+#else
+            asm volatile("" :: "v"(v), "v"(base));
+#endif
         }
     };
     uint32_t sqh = 0u;               // fp16 stash: the first packed pair of the four features being collected
@@ -128,7 +132,11 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int ut = decltype(utc)::value;
         constexpr int r = decltype(rc)::value;
         if constexpr ((r & 3) == 0) sqh = ph;
+#ifndef NERF_DIAG_NO_STASH_STORES
         else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * (32 * ut + 8 * (r >> 2))) = make_uint2(sqh, ph);
+#else
+        else asm volatile("" :: "v"(sqh), "v"(ph), "v"(base));
+#endif
     };
     auto store_pair = [&](auto utc, auto rc, float y0, float y1, auto dest_sel, auto pend_sel) {
         constexpr int ut = decltype(utc)::value;
