@@ -26,8 +26,12 @@ int main(int argc, char** argv) {
     /* a wrong blob size must be refused with a message, not crash */
     if (nerf_load_weights(ctx, NERF_NET_COARSE, buf, nb - 1) == 0) { fprintf(stderr, "size check missing\n"); return 1; }
     const int H = 16, W = 16;
-    float* rgb = (float*)malloc(sizeof(float) * H * W * 3);
-    float* depth = (float*)malloc(sizeof(float) * H * W);
+    /* page-locked outputs (ABI 3: nerf_host_alloc): the device writes them by DMA beside the kernels */
+    float *rgb = NULL, *depth = NULL;
+    if (nerf_abi_version() != NERF_ABI_VERSION || nerf_host_alloc(sizeof(float) * H * W * 3, (void**)&rgb) ||
+        nerf_host_alloc(sizeof(float) * H * W, (void**)&depth)) {
+        fprintf(stderr, "host_alloc: %s\n", nerf_last_error()); return 1;
+    }
     nerf_outputs out = {0};
     out.rgb = rgb; out.depth = depth;
     if (nerf_render_image(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 0, 0, 64, 128, NULL, NULL, 12345u, &out, NERF_MEM_HOST)) {
@@ -75,9 +79,25 @@ int main(int argc, char** argv) {
             fprintf(stderr, "train: %s\n", nerf_last_error()); return 1;
         }
         printf("train_loss %.9g %.9g\n", m0[0], m1[0]);
+        /* the same under the reference's production policy: mixed_float16 with dynamic loss scaling; an infinite target is a
+         * SKIPPED step that halves the scale (ABI 2/3) */
+        nerf_train_config tm = {5e-4f, 0.9f, 0.999f, 1e-7f, 1, 1, 1024.0f, 0};
+        float scale = 0.f;
+        int64_t applied = -1, skipped = -1;
+        if (nerf_train_begin(ctx, &tm) ||
+            nerf_train_step(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 2u, m0, NERF_MEM_HOST)) {
+            fprintf(stderr, "train mixed: %s\n", nerf_last_error()); return 1;
+        }
+        tgt[0] = INFINITY;
+        if (nerf_train_step(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 3u, m1, NERF_MEM_HOST) ||
+            nerf_train_loss_scale(ctx, &scale, &applied, &skipped) || nerf_train_end(ctx)) {
+            fprintf(stderr, "train mixed: %s\n", nerf_last_error()); return 1;
+        }
+        printf("mixed %.9g %g %lld %lld\n", m0[0], scale, (long long)applied, (long long)skipped);
         free(dirs); free(orig); free(tgt);
     }
     nerf_ctx_destroy(ctx);
-    free(buf); free(rgb); free(depth);
+    nerf_host_free(rgb); nerf_host_free(depth);
+    free(buf);
     return 0;
 }

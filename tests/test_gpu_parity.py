@@ -640,6 +640,9 @@ def test_c_abi_client(tmp_path, oracle):
     assert re.search(r"sharded_equal 1", res.stdout), res.stdout
     tl = re.search(r"train_loss (\S+) (\S+)", res.stdout)
     assert tl and 0 < float(tl.group(2)) < float(tl.group(1)), res.stdout
+    # ... and through the mixed_float16 policy: one applied step, then an infinite target = a skipped step and half the scale
+    mx = re.search(r"mixed (\S+) (\S+) (\S+) (\S+)", res.stdout)
+    assert mx and np.isfinite(float(mx.group(1))) and (float(mx.group(2)), int(mx.group(3)), int(mx.group(4))) == (512.0, 1, 1), res.stdout
 
 
 def test_nonfinite_watch(golden_ckpt, golden_vec):
