@@ -76,7 +76,8 @@ class _PinnedPool:
         import threading
         self.free: List[Tuple[int, int]] = []        # (cap, ptr)
         self.keep_bytes, self.free_bytes = keep_bytes, 0
-        self.lock = threading.Lock()
+        # re-entrant: a garbage collection inside take() may run a dead block's __del__ -> _give_back on this same thread
+        self.lock = threading.RLock()
 
     def take(self, shape) -> np.ndarray:
         n = int(np.prod(shape, dtype=np.int64))
