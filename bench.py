@@ -365,13 +365,13 @@ def main():
     # the training step on the reference's batch, timed briefly beside the headline (N=1 only)
     train = None
     if world == 1 and args.rehearse_world <= 1 and not args.no_train:
-        n_tr, k_tr = 4096, 10
+        n_tr, k_tr = 4096, 30
         gen = torch.Generator(device="cuda").manual_seed(0)
         t_o = torch.zeros((n_tr, 4), device="cuda"); t_o[:, 2] = 1.0; t_o[:, 3] = 1.0
         t_d = torch.randn((n_tr, 4), device="cuda", generator=gen) * 0.3; t_d[:, 2] = -1.0; t_d[:, 3] = 0.0
         t_rgb = torch.rand((n_tr, 3), device="cuda", generator=gen)
         model.compile(5e-4)
-        for i in range(2):
+        for i in range(3):
             model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=i, want_metrics=False)
         sync()
         t2 = time.perf_counter()
@@ -383,7 +383,7 @@ def main():
         model.ctx.train_end()
         # the reference's production policy (mixed_float16 + dynamic loss scaling) on the same batch
         model.compile(5e-4, mixed_float16=True)
-        for i in range(2):
+        for i in range(3):
             model.ctx.train_step(t_o, t_d, t_rgb, SC, SF, seed=i, want_metrics=False)
         sync()
         t2m = time.perf_counter()
