@@ -155,7 +155,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     auto store4 = [&](float* base, int c0, int r, float v, auto fragc) {
         f32x4 o;
         o[0] = q0; o[1] = q1; o[2] = q2; o[3] = v;
-        *reinterpret_cast<f32x4*>(base + (decltype(fragc)::value ? 32 : 1) * (c0 + 8 * (r >> 2))) = o;
+        stream_store(reinterpret_cast<f32x4*>(base + (decltype(fragc)::value ? 32 : 1) * (c0 + 8 * (r >> 2))), o);
     };
     // register r of hidden tile ht: mask, write the true value, scale + split + pack into the next operand
     // alpha folded into the four scales once per body (pinned: left to itself hipcc re-multiplies per value rather than
@@ -190,8 +190,8 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             // LossScaleOptimizer logic skips the step and halves the scale.
             if constexpr ((r & 1) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = __uint_as_float(pack_h2(q0, t));
-            else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))) =
-                     make_uint2(__float_as_uint(q1), pack_h2(q0, t));
+            else stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))),
+                              make_uint2(__float_as_uint(q1), pack_h2(q0, t)));
         } else {
             if constexpr ((r & 3) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = t;
@@ -392,7 +392,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         const f32x4 graw = *reinterpret_cast<const f32x4*>(a.graw + m * 4);
         frag4 mq[NMQ];
 #pragma unroll
-        for (int l = 0; l < NMQ; ++l) mq[l] = *(reinterpret_cast<const frag4*>(a.mask_ptr[NMQ - 1 - l]) + m * 2 + h);
+        for (int l = 0; l < NMQ; ++l)       // (read once: non-temporal, like the stash stores)
+            mq[l] = __builtin_nontemporal_load(reinterpret_cast<const frag4*>(a.mask_ptr[NMQ - 1 - l]) + m * 2 + h);
         // mq[0] = mask of h9 (layer 8's output), mq[1] = h8, ..., mq[8] = h1 (layer 0's output); the xyz-only network has
         // its extra layer's record at mq[1] and everything else one further down
 
@@ -419,10 +420,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     mt = fmaxf(mt, fabsf(v));
                 }
                 if constexpr (FAST)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[NMQ - 1]) + off128 + 32 * (32 * t + 16 * s + 8 * g)) =
-                        make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
+                    stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[NMQ - 1]) + off128 + 32 * (32 * t + 16 * s + 8 * g)),
+                                 make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3])));
                 else
-                    *reinterpret_cast<f32x4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s + 8 * g)) = o;
+                    stream_store(reinterpret_cast<f32x4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s + 8 * g)), o);
             }
         }
         mt = max_with_other_half(mt);
@@ -524,10 +525,10 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                     tmax = fmaxf(tmax, fabsf(v));
                 }
                 if constexpr (FAST)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * (32 * 7 + 8 * (r >> 2))) =
-                        make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3]));
+                    stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * (32 * 7 + 8 * (r >> 2))),
+                                 make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3])));
                 else
-                    *reinterpret_cast<f32x4*>(d_cur + 32 * (32 * 7 + 8 * (r >> 2))) = o;
+                    stream_store(reinterpret_cast<f32x4*>(d_cur + 32 * (32 * 7 + 8 * (r >> 2))), o);
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);

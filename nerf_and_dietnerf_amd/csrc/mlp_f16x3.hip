@@ -120,7 +120,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             f32x4 v;
             v[0] = sq0; v[1] = sq1; v[2] = y0; v[3] = y1;
 #ifndef NERF_DIAG_NO_STASH_STORES   // timing-only diagnostic: everything but the store instruction itself
-            *reinterpret_cast<f32x4*>(base + 32 * (32 * ut + 8 * (r >> 2))) = v;
+            stream_store(reinterpret_cast<f32x4*>(base + 32 * (32 * ut + 8 * (r >> 2))), v);
 #else
             asm volatile("" :: "v"(v), "v"(base));
 #endif
@@ -133,7 +133,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         constexpr int r = decltype(rc)::value;
         if constexpr ((r & 3) == 0) sqh = ph;
 #ifndef NERF_DIAG_NO_STASH_STORES
-        else *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * (32 * ut + 8 * (r >> 2))) = make_uint2(sqh, ph);
+        else stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + 32 * (32 * ut + 8 * (r >> 2))), make_uint2(sqh, ph));
 #else
         else asm volatile("" :: "v"(sqh), "v"(ph), "v"(base));
 #endif
@@ -255,7 +255,7 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 else store_pair(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry, y, std::false_type{}, std::false_type{});
             }
             if constexpr (u == 0 && PENDING) {
-                if constexpr (STASH && n == 8) { if (mk_prev_ptr) *mk_prev_ptr = mk_prev; }   // that layer's mask word is complete
+                if constexpr (STASH && n == 8) { if (mk_prev_ptr) stream_store(mk_prev_ptr, mk_prev); }   // that layer's mask word is complete
                 // previous layer's tile 6 sits complete in nh/nl[12..13]; its k-steps are long retired
                 if constexpr (n == 8) { xh[12] = nh[12]; xl[12] = nl[12]; }
                 if constexpr (n == 9) { xh[13] = nh[13]; xl[13] = nl[13]; }
@@ -297,13 +297,13 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 else stash4(std::integral_constant<int, NU - 1>{}, std::integral_constant<int, r>{}, y0, y1, st_cur);
                 mk_cur[(NU - 1) >> 1] = mask_push(mk_cur[(NU - 1) >> 1], pp);
             });
-            if (mk_cur_ptr) *mk_cur_ptr = mk_cur;      // the 128-wide layer's record is complete
+            if (mk_cur_ptr) stream_store(mk_cur_ptr, mk_cur);      // the 128-wide layer's record is complete
         }
     }
     if constexpr (BODY == BODY_LAST) {
         // sigma row: feature row 0 of tile 4 = register 0 of lane half 0; raw, no activation (NeRF.py:336)
         sigma_raw = accs[(NU - 1) & 3][0];
-        if constexpr (STASH) { if (mk_cur_ptr) *mk_cur_ptr = mk_cur; }   // layer 8 (128 features): all four tiles are finished
+        if constexpr (STASH) { if (mk_cur_ptr) stream_store(mk_cur_ptr, mk_cur); }   // layer 8 (128 features): all four tiles are finished
     }
     if constexpr (NQ % kHCQ != 0 && NQ % kHCQ <= kHCQ / 2) pipe_sync_c<kHCQ, kHRing, 1, kStashExtra>(p);
     p.ck += 1;
