@@ -34,41 +34,63 @@ namespace nerf {
 // (NERF_BWD_CQ=16: 16 KiB chunks in 8 slots, 20 operations of slack instead of 8) was built to widen that window and
 // measured 1.7 % SLOWER per training step (12.05 vs 11.84 ms): the window is not what bounds the stores
 // (L2 bandwidth shared with the weight stream is).  The render kernels' 32 KiB x 4 stays.
+//
+// The single-pass kernels (mixed_float16 policy) carry half the operand registers of the 3-pass ones and fit 256, so two
+// workgroups per CU are possible, each on its own 64 KiB ring of 16 KiB chunks (NERF_BWD_FAST_OCC=2): built and measured
+// 2 % SLOWER per mixed_float16 step (4.26 vs 4.16 ms, same device) -- a second wave per SIMD hides waits, and waits are not
+// what this kernel is short of: its vector instructions (10 per MFMA) and its MFMAs do not overlap, and two waves share
+// one VALU.  The default stays one workgroup per CU.
 #ifndef NERF_BWD_CQ
 #define NERF_BWD_CQ 32
 #endif
-constexpr int kBCQ = NERF_BWD_CQ;               // quads per chunk
-constexpr int kBRing = kRingBytes / (kBCQ * kQuadBytes);
-constexpr int kBChunkBytes = kBCQ * kQuadBytes;
-static_assert(kBRing * kBChunkBytes == kRingBytes && (kBRing & (kBRing - 1)) == 0, "ring must fill the LDS carve");
+#ifndef NERF_BWD_FAST_OCC
+#define NERF_BWD_FAST_OCC 1
+#endif
+template <bool FAST>
+struct BGeo {
+    static constexpr int Occ = FAST ? NERF_BWD_FAST_OCC : 1;                 // workgroups per CU
+    static constexpr int CQ = Occ == 2 ? 16 : NERF_BWD_CQ;                    // quads per chunk
+    static constexpr int RingBytes = kRingBytes / Occ;
+    static constexpr int ChunkBytes = CQ * kQuadBytes;
+    static constexpr int Ring = RingBytes / ChunkBytes;
+    static constexpr int LdsConst = kLdsRing + RingBytes;                     // the constant block follows the ring
+    static constexpr int LdsGmax = LdsConst + (kConstFloats - 16) * 4;        // 9 (xyz-only network: 10) x uint32: max|D| bits per gradient buffer
+    static constexpr int LdsTotal = RingBytes + kConstBytes;
+    static constexpr int NAcc = Occ == 2 ? 2 : 4;                             // rotating accumulator tiles
+    static constexpr int Pf = FAST ? (Occ == 2 ? 4 : 8) : 4;                  // LDS fragment reads in flight
+    static_assert(Ring * ChunkBytes == RingBytes && (Ring & (Ring - 1)) == 0, "ring must fill its LDS carve");
+    static_assert(Occ * LdsTotal <= 160 * 1024, "workgroups of one CU must share 160 KiB");
+};
 
 // ---- stream geometry: bodies in execution order, each padded to whole chunks ----
 constexpr int kBStepsHead = 9;                 // 128 features of G9 (8 k-steps) + 1 k-step carrying d_sigma
-constexpr int kBChunksHead = (8 * 2 * kBStepsHead + kBCQ - 1) / kBCQ;     // 144 quads -> 5
-constexpr int kBChunksHid = (8 * 2 * 16) / kBCQ;                          // 8
-constexpr int kBChunksHidX = ((8 + 2) * 2 * 16) / kBCQ;                   // 10: layer 4 with its two encoding tiles
-constexpr int kBChunksXyz = (2 * 2 * 16) / kBCQ;                          // 2: layer 0's encoding rows
-constexpr int kBStreamChunks = kBChunksHead + 7 * kBChunksHid;                                  // 61
-constexpr int kBStreamChunksDx = kBChunksHead + 6 * kBChunksHid + kBChunksHidX + kBChunksXyz;   // 65
-static_assert((size_t)kBStreamChunksDx * kBChunkBytes <= kBwdStreamBytes, "backward stream does not fit its buffer");
-// single-pass variant (mixed_float16 policy): hi fragments only, one quad per k-step
-constexpr int kBFChunksHead = (8 * kBStepsHead + kBCQ - 1) / kBCQ;        // 72 quads -> 3
-constexpr int kBFChunksHid = (8 * 16) / kBCQ;                             // 4
-constexpr int kBFChunksHidX = ((8 + 2) * 16) / kBCQ;                      // 5
-constexpr int kBFChunksXyz = (2 * 16) / kBCQ;                             // 1
-constexpr int kBFStreamChunks = kBFChunksHead + 7 * kBFChunksHid;                                   // 31
-constexpr int kBFStreamChunksDx = kBFChunksHead + 6 * kBFChunksHid + kBFChunksHidX + kBFChunksXyz;   // 33
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+// chunks of the stream of one kernel variant (3-pass: hi + lo fragment per k-step; single-pass: hi only)
+template <bool FAST>
+constexpr int bwd_stream_chunks(bool dx, bool xyz) {
+    constexpr int CQ = BGeo<FAST>::CQ, T = FAST ? 1 : 2;
+    const int head = cdiv(8 * T * kBStepsHead, CQ), hid = cdiv(8 * T * 16, CQ);
+    const int hidx = cdiv(10 * T * 16, CQ), enc = cdiv(2 * T * 16, CQ);   // layer 4 with its two encoding tiles; layer 0's encoding rows
+    return head + (dx ? 6 * hid + hidx + enc : 7 * hid) + (xyz ? hid : 0);   // the xyz-only network has one more 256 x 256 body
+}
+static_assert((size_t)bwd_stream_chunks<false>(true, true) * BGeo<false>::ChunkBytes <= kBwdStreamBytes &&
+              (size_t)bwd_stream_chunks<true>(true, true) * BGeo<true>::ChunkBytes <= kBwdStreamBytes,
+              "backward stream does not fit its buffer");
 
 constexpr int kBConstWrgb = 2208;     // the forward kernel's constant block is reused: [3][128] rgb head weights
 constexpr int kBConstFloats = 2608;
-constexpr int kBLdsGmax = kLdsConst + (kConstFloats - 16) * 4;   // 9 (xyz-only network: 10) x uint32: max|D| bits per gradient buffer
 static_assert(kBConstFloats + 16 <= kConstFloats && kXConstFloats + 16 <= kConstFloats, "gmax slots must fit the shared LDS carve");
 
 enum { BW_HEAD = 0, BW_HID = 1, BW_XYZ = 2 };
 
-__device__ __forceinline__ uint32_t* lds_gmax() {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    return reinterpret_cast<uint32_t*>(smem + kBLdsGmax);
+// max|D| slot k of the workgroup: a plain ds_max_u32 from every lane (one address: the LDS takes the 64 lanes one after
+// the other, in ITS cycles; the wave does not wait for a no-return atomic).  Written as atomicMax(), hipcc's atomic
+// optimizer turns it into a scalar loop over the 64 lanes (s_ff1 / v_readlane / s_max, ~50 cycles a turn) in the middle of
+// the MFMA chain, once per body: a fifth of the single-pass kernel's time.  (The dynamic LDS segment starts at address 0,
+// as the asm fragment reads assume as well.)
+template <bool FAST>
+__device__ __forceinline__ void lds_gmax_update(int slot, uint32_t bits) {
+    asm volatile("ds_max_u32 %0, %1" : : "v"((uint32_t)(BGeo<FAST>::LdsGmax + 4 * slot)), "v"(bits) : "memory");
 }
 
 struct BwdLane {          // per-lane (= per-sample) scale state
@@ -116,7 +138,7 @@ __device__ __forceinline__ float mask_select(int m, float neg, float pos) {
 template <int KIND, int NX, bool PEND, bool FAST, bool SIG = false, bool SIGP = false>
 __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, BwdLane& L, bool copy_tail,
                                          float* d_prev, float* d_cur, float* dx_cur, const frag4& mk_prev,
-                                         const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[4], frag4 (&xh)[16],
+                                         const frag4& mk_cur, int gslot_prev, f32x16 (&accs)[BGeo<FAST>::NAcc], frag4 (&xh)[16],
                                          frag4 (&xl)[16], frag4 (&nh)[14], frag4 (&nl)[14], float d_sigma = 0.f,
                                          uint32_t cb_h = 0u) {
 #ifndef NERF_BWD_EXTRA_FAST
@@ -132,7 +154,8 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     constexpr int TPS = FAST ? 1 : 2;
     constexpr int QPU = TPS * NSTEP;
     constexpr int NQ = NU * QPU;
-    constexpr int kPf = FAST ? 8 : 4;
+    using G = BGeo<FAST>;
+    constexpr int kBCQ = G::CQ, kBRing = G::Ring, kBChunkBytes = G::ChunkBytes, kPf = G::Pf, NA = G::NAcc;
     f32x4 pf[kPf];
     const int ck0 = p.ck;
     uint32_t rdbase[2];
@@ -229,11 +252,11 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
 
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        // accumulators rotate so that every body's LAST tile ends in accs[3]: that is where the next body's pending
+        // accumulators rotate so that every body's LAST tile ends in accs[NA - 1]: that is where the next body's pending
         // epilogue (u == 0) looks for it, whatever the tile count
-        constexpr int kOff = (4 - NU % 4) & 3;
-        f32x16& acc = accs[(u + kOff) & 3];
-        f32x16& prv = accs[u == 0 ? 3 : (u + kOff + 3) & 3];
+        constexpr int kOff = (NA - NU % NA) % NA;
+        f32x16& acc = accs[(u + kOff) % NA];
+        f32x16& prv = accs[u == 0 ? NA - 1 : (u + kOff + NA - 1) % NA];
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             f32x4 araw[2];
@@ -300,7 +323,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                     L.rho = pow2_to_peak(SIG ? fmaxf(m_in, fabsf(dsig_cur)) : m_in);
                     arho_cur = pinned(alpha * L.rho);
                     L.mrun = 0.f;
-                    atomicMax(lds_gmax() + gslot_prev, __float_as_uint(m_in * L.inv_sig));
+                    lds_gmax_update<FAST>(gslot_prev, __float_as_uint(m_in * L.inv_sig));
                     if (copy_tail) { xh[12] = nh[12]; xl[12] = nl[12]; }
                 }
                 if constexpr (n == 9) { if (copy_tail) { xh[13] = nh[13]; xl[13] = nl[13]; } }
@@ -332,7 +355,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         });
     });
     if constexpr (KIND == BW_XYZ) {      // end of the chain: the last encoding tile's epilogue has no chain to ride on
-        f32x16& last = accs[3];
+        f32x16& last = accs[NA - 1];
         static_for<0, 16>([&](auto rc) {
             xyz_reg(std::integral_constant<int, NU - 1>{}, rc, last[decltype(rc)::value]);
         });
@@ -344,6 +367,8 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
 template <bool DX, bool FAST, bool XYZ = false>
 __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     constexpr int NMQ = XYZ ? 10 : 9;           // mask records / gradient buffers of the network
+    using G = BGeo<FAST>;
+    constexpr int kBCQ = G::CQ, kBRing = G::Ring, kBChunkBytes = G::ChunkBytes;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -351,20 +376,19 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     const uint32_t lane16 = kLdsRing + lane * 16;
-    const uint32_t cb_h = kLdsConst + h * 16;
+    const uint32_t cb_h = G::LdsConst + h * 16;
 
     const long long ntiles = a.Mp / 128;
     if ((long long)blockIdx.x >= ntiles) return;
 
     for (int i = tid; i < (XYZ ? kXConstFloats : kBConstFloats) / 4; i += 256)
-        reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
-    if (tid < 16) reinterpret_cast<uint32_t*>(smem + kBLdsGmax)[tid] = 0u;
+        reinterpret_cast<f32x4*>(smem + G::LdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + G::LdsGmax)[tid] = 0u;
 
     Pipe p;
     p.ck = 0;
     p.src_next = 0;
-    p.n_chunks = (FAST ? (DX ? kBFStreamChunksDx : kBFStreamChunks) : (DX ? kBStreamChunksDx : kBStreamChunks)) +
-                 (XYZ ? (FAST ? kBFChunksHid : kBChunksHid) : 0);     // the xyz-only network has one more 256 x 256 body
+    p.n_chunks = bwd_stream_chunks<FAST>(DX, XYZ);
     p.wbase = reinterpret_cast<const char*>(a.wstream);
     p.voff = wave * (kBCQ / 4 * kQuadBytes) + lane * 16;
     p.wave_lds = wave * (kBCQ / 4 * kQuadBytes);
@@ -382,7 +406,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     asm volatile("" ::: "memory");
 
     frag4 xh[16], xl[16], nh[14], nl[14];
-    f32x16 accs[4];
+    f32x16 accs[G::NAcc];
     const float alpha = a.alpha;
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -427,7 +451,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             }
         }
         mt = max_with_other_half(mt);
-        atomicMax(lds_gmax() + 0, __float_as_uint(mt));
+        lds_gmax_update<FAST>(0, __float_as_uint(mt));
         const float m_true = XYZ ? mt : fmaxf(mt, fabsf(graw[3]));   // (xyz-only: d_sigma enters one body later)
         BwdLane L;
         const float sig = pow2_to_peak(m_true);
@@ -512,7 +536,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             bwd_body<BW_XYZ, 2, true, FAST>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, NMQ - 1, accs, xh, xl, nh, nl);
         } else {
             // flush: D0's last tile has no chain to ride on; nothing is packed any more
-            f32x16& last = accs[3];
+            f32x16& last = accs[G::NAcc - 1];
             float tmax = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
@@ -532,13 +556,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);
-            atomicMax(lds_gmax() + NMQ - 1, __float_as_uint(max_with_other_half(tmax)));
+            lds_gmax_update<FAST>(NMQ - 1, __float_as_uint(max_with_other_half(tmax)));
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: the asm ds_max_u32 updates of the gmax slots)
     __syncthreads();
     if (tid < NMQ && a.gmax) {
-        const uint32_t v = reinterpret_cast<const uint32_t*>(smem + kBLdsGmax)[tid];
+        const uint32_t v = reinterpret_cast<const uint32_t*>(smem + G::LdsGmax)[tid];
         unsigned* slot = a.gmax + 64 * tid + (blockIdx.x & 63);
         if (v > *slot) atomicMax(slot, v);
     }
@@ -546,29 +570,31 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, false>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, false>(a); }
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true>(a); }
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true>(a); }
+__global__ __launch_bounds__(256, BGeo<true>::Occ) void mlp_bwd_f16_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true>(a); }
+__global__ __launch_bounds__(256, BGeo<true>::Occ) void mlp_bwd_f16_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true>(a); }
 // the xyz-only network (n_angles_for_model = 0): one more 256-wide body, sigma's rank-1 term one body later
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_xyz_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f16x3_xyz_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, false, true>(a); }
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_xyz_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true, true>(a); }
-__global__ __launch_bounds__(256, 1) void mlp_bwd_f16_xyz_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true, true>(a); }
+__global__ __launch_bounds__(256, BGeo<true>::Occ) void mlp_bwd_f16_xyz_kernel(const MlpBwdArgs a) { mlp_bwd_body<false, true, true>(a); }
+__global__ __launch_bounds__(256, BGeo<true>::Occ) void mlp_bwd_f16_xyz_dx_kernel(const MlpBwdArgs a) { mlp_bwd_body<true, true, true>(a); }
 
 void launch_mlp_bwd_f16x3(const MlpBwdArgs& a, bool dx, bool single_pass, int num_cus, hipStream_t stream, bool xyz_only) {
     if (a.Mp <= 0) return;
     const long long ntiles = a.Mp / 128;
-    const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
+    const long long slots = (long long)num_cus * (single_pass ? BGeo<true>::Occ : 1);      // resident workgroups
+    const int grid = (int)(ntiles < slots ? ntiles : slots);
     auto* k = xyz_only ? (single_pass ? (dx ? mlp_bwd_f16_xyz_dx_kernel : mlp_bwd_f16_xyz_kernel)
                                       : (dx ? mlp_bwd_f16x3_xyz_dx_kernel : mlp_bwd_f16x3_xyz_kernel))
               : single_pass ? (dx ? mlp_bwd_f16_dx_kernel : mlp_bwd_f16_kernel)
                             : (dx ? mlp_bwd_f16x3_dx_kernel : mlp_bwd_f16x3_kernel);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), single_pass ? BGeo<true>::LdsTotal : BGeo<false>::LdsTotal, stream, a);
 }
 
 void mlp_bwd_f16x3_set_attributes() {
-    for (auto* k : {mlp_bwd_f16x3_kernel, mlp_bwd_f16x3_dx_kernel, mlp_bwd_f16_kernel, mlp_bwd_f16_dx_kernel,
-                    mlp_bwd_f16x3_xyz_kernel, mlp_bwd_f16x3_xyz_dx_kernel, mlp_bwd_f16_xyz_kernel, mlp_bwd_f16_xyz_dx_kernel})
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    for (auto* k : {mlp_bwd_f16x3_kernel, mlp_bwd_f16x3_dx_kernel, mlp_bwd_f16x3_xyz_kernel, mlp_bwd_f16x3_xyz_dx_kernel})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, BGeo<false>::LdsTotal);
+    for (auto* k : {mlp_bwd_f16_kernel, mlp_bwd_f16_dx_kernel, mlp_bwd_f16_xyz_kernel, mlp_bwd_f16_xyz_dx_kernel})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, BGeo<true>::LdsTotal);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -587,10 +613,12 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
     const int (*shapes)[2] = xyz_only ? shapes_xyz : shapes_dir;
     long long koff[12], off = 0;
     for (int i = 0; i < 12; ++i) { koff[i] = off; off += (long long)shapes[i][0] * shapes[i][1] + shapes[i][1]; }
+    const int cq = hi_only ? BGeo<true>::CQ : BGeo<false>::CQ;        // the two arithmetics run different ring geometries
+    const int chunk_halfs = cq * (kQuadBytes / 2);
     size_t chunk = 0;
     // one body: NU tiles x NSTEP k-steps; src(u, i, n, e, h) gives the blob index of A[i][k] or -1
     auto emit = [&](int NU, int NSTEP, auto src) {
-        const long long b0 = (long long)chunk * (kBChunkBytes / 2);
+        const long long b0 = (long long)chunk * chunk_halfs;
         for (int u = 0; u < NU; ++u)
             for (int n = 0; n < NSTEP; ++n)
                 for (int lane = 0; lane < 64; ++lane)
@@ -605,7 +633,7 @@ void build_bwd_gather(int n_angles, bool dx, bool hi_only, int32_t* idx /* kBwdS
                         idx[b0 + (q + 0) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1));
                         idx[b0 + (q + 1) * (kQuadBytes / 2) + lane * 8 + e] = (int32_t)(2 * (s + 1) + 1);
                     }
-        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + kBCQ - 1) / kBCQ;
+        chunk += (NU * NSTEP * (hi_only ? 1 : 2) + cq - 1) / cq;
     };
     // layer 8 transposed (+ the sigma head's hidden rows as the 9th k-step); xyz-only network: layer 9 (256 -> 128)
     // transposed, the 9th k-step multiplies zeros (its sigma term is added one body later, on the VALU)
