@@ -191,8 +191,19 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
     const float dsig_cur = SIG ? d_sigma * pow2_inverse(L.inv_sig) : 0.f;
     const float dsig_prev = SIGP ? d_sigma * pow2_inverse(L.inv_prev) : 0.f;
     (void)dsig_cur; (void)dsig_prev;
+    // single-pass: the stored D pair is the packed operand pair times inv / rho, a power of two -- one v_pk_mul_f16 per
+    // PAIR instead of a second select + multiply per value and a second conversion per pair (the product is exact unless
+    // it lands below 2^-14; a ratio beyond the fp16 range becomes Inf / 0: the former means the true D overflowed fp16
+    // anyway -- the step is skipped and the loss scale halved -- the latter that |D| < 2^-18 for the whole sample)
+    auto ratio_h2 = [](float inv, float rho) {
+        const _Float16 r = (_Float16)(inv * pow2_inverse(rho));
+        return h2{r, r};
+    };
+    const h2 rat_prev = ratio_h2(L.inv_prev, L.rho_prev);
+    h2 rat_cur = ratio_h2(L.inv_sig, L.rho);          // renewed with L.rho
+    (void)rat_prev; (void)rat_cur;
     auto hidden_reg = [&](auto htc, auto rc, float acc_in, const frag4& mk, float inv_s, float rho_s, float ainv_s,
-                          float arho_s, float* dst, auto to_x, auto sig_sel) {
+                          float arho_s, h2 rat_s, float* dst, auto to_x, auto sig_sel) {
         constexpr int ht = decltype(htc)::value;
         constexpr int r = decltype(rc)::value;
         float acc_v = acc_in;
@@ -204,24 +215,20 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         }
         // t = acc * LeakyReLU' / scale-in (the true value), pk = acc * LeakyReLU' * scale-out (the next operand): LeakyReLU'
         // is folded into the two power-of-two scales (exact), one selected factor each -- bfe + 2 bfi + 2 mul where
-        // and + compare + select + three multiplications were 6 VALU ops per value
+        // and + compare + select + three multiplications were 6 VALU ops per value (single-pass: t comes from the packed
+        // pair, see ratio_h2: bfe + bfi + mul per value)
         const int neg = mask_ones<mask_bit(ht, r)>(mk[ht >> 1]);
-        const float t = acc_v * mask_select(neg, ainv_s, inv_s);
-        if constexpr (FAST) {
-            // mixed_float16 policy: D is stored in fp16 (dst points at fp16 rows).  The values carry the loss scale, as
-            // the policy's activation gradients do: an overflow becomes Inf here, NaN in the weight gradient, and the
-            // LossScaleOptimizer logic skips the step and halves the scale.
-            if constexpr ((r & 1) == 0) q0 = t;
-            else if constexpr ((r & 3) == 1) q1 = __uint_as_float(pack_h2(q0, t));
-            else stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))),
-                              make_uint2(__float_as_uint(q1), pack_h2(q0, t)));
-        } else {
+        float pk;
+        if constexpr (!FAST) {
+            const float t = acc_v * mask_select(neg, ainv_s, inv_s);
             if constexpr ((r & 3) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = t;
             else if constexpr ((r & 3) == 2) q2 = t;
             else store4(dst, 32 * ht, r, t, std::true_type{});
         }
-        const float pk = acc_v * mask_select(neg, arho_s, rho_s);
+        // (pk = t * (rho / inv) would save the second select, but a sample whose gradient underflows has inv = 0 and
+        // rho / inv = Inf: 0 * Inf poisoned the weight gradients -- measured, reverted)
+        pk = acc_v * mask_select(neg, arho_s, rho_s);
         L.mrun = fmaxf(L.mrun, fabsf(pk));
         if constexpr ((r & 1) == 0) pc = pk;
         else {
@@ -230,6 +237,13 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                 const uint32_t ph = pack_h2(pc, pk);
                 if constexpr (decltype(to_x)::value) xh[n][d] = ph;
                 else nh[n][d] = ph;
+                // mixed_float16 policy: D is stored in fp16 (dst points at fp16 rows).  The values carry the loss scale, as
+                // the policy's activation gradients do: an overflow becomes Inf here, NaN in the weight gradient, and the
+                // LossScaleOptimizer logic skips the step and halves the scale.
+                const uint32_t tp = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, ph) * rat_s);
+                if constexpr ((r & 3) == 1) q1 = __uint_as_float(tp);
+                else stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))),
+                                  make_uint2(__float_as_uint(q1), tp));
             } else {
                 float h0, l0, h1, l1;
                 split_trunc(pc, h0, l0);
@@ -308,10 +322,10 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             if constexpr (u == 0 && PEND) {
                 if constexpr (n < 8) {           // previous body's hidden tile 7, a register pair per k-step
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                               mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{},
+                               mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, rat_prev, d_prev, std::true_type{},
                                std::integral_constant<int, SIGP ? 2 : 0>{});
                     hidden_reg(std::integral_constant<int, 7>{}, std::integral_constant<int, 2 * n + 1>{},
-                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, d_prev, std::true_type{},
+                               prv[2 * n + 1], mk_prev, L.inv_prev, L.rho_prev, ainv_prev, arho_prev, rat_prev, d_prev, std::true_type{},
                                std::integral_constant<int, SIGP ? 2 : 0>{});
                 }
                 if constexpr (n == 8) {
@@ -322,6 +336,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                     // with only the operand's peak a ray whose colour gradient vanishes overflowed the fp16 packing)
                     L.rho = pow2_to_peak(SIG ? fmaxf(m_in, fabsf(dsig_cur)) : m_in);
                     arho_cur = pinned(alpha * L.rho);
+                    rat_cur = ratio_h2(L.inv_sig, L.rho);
                     L.mrun = 0.f;
                     lds_gmax_update<FAST>(gslot_prev, __float_as_uint(m_in * L.inv_sig));
                     if (copy_tail) { xh[12] = nh[12]; xl[12] = nl[12]; }
@@ -336,14 +351,14 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                     constexpr int ht = pt - NX;
                     if constexpr (NSTEP >= 16) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, n>{}, prv[n], mk_cur,
-                                   L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
+                                   L.inv_sig, L.rho, ainv_cur, arho_cur, rat_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
                                    std::integral_constant<int, SIG ? 1 : 0>{});
                     } else if constexpr (n < 8) {
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n>{}, prv[2 * n],
-                                   mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
+                                   mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, rat_cur, d_cur, std::integral_constant<bool, KIND == BW_HEAD>{},
                                    std::integral_constant<int, SIG ? 1 : 0>{});
                         hidden_reg(std::integral_constant<int, ht>{}, std::integral_constant<int, 2 * n + 1>{},
-                                   prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, d_cur,
+                                   prv[2 * n + 1], mk_cur, L.inv_sig, L.rho, ainv_cur, arho_cur, rat_cur, d_cur,
                                    std::integral_constant<bool, KIND == BW_HEAD>{}, std::integral_constant<int, SIG ? 1 : 0>{});
                     }
                 }
