@@ -206,6 +206,12 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                           float arho_s, h2 rat_s, float* dst, auto to_x, auto sig_sel) {
         constexpr int ht = decltype(htc)::value;
         constexpr int r = decltype(rc)::value;
+#if defined(NERF_DIAG_BWD_EPI) && NERF_DIAG_BWD_EPI <= 2   // timing-only diagnostics (wrong results): 2 = the value is moved out of
+        if constexpr (FAST) {                               // its accumulator and dropped, 1 = one move per 16 values
+            if constexpr (NERF_DIAG_BWD_EPI == 2 || r == 15) asm volatile("" : : "v"(acc_in));
+            return;
+        }
+#endif
         float acc_v = acc_in;
         if constexpr (decltype(sig_sel)::value != 0) {
             // feature 32 ht + 8 (r >> 2) + 4 h + (r & 3) of this lane (cb_h carries the 4 h)
@@ -242,8 +248,12 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                 // LossScaleOptimizer logic skips the step and halves the scale.
                 const uint32_t tp = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, ph) * rat_s);
                 if constexpr ((r & 3) == 1) q1 = __uint_as_float(tp);
+#if defined(NERF_DIAG_BWD_EPI) && NERF_DIAG_BWD_EPI == 3     // timing-only: everything but the store instruction
+                else asm volatile("" : : "v"(q1), "v"(tp), "v"(dst));
+#else
                 else stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + 32 * (32 * ht + 8 * (r >> 2))),
                                   make_uint2(__float_as_uint(q1), tp));
+#endif
             } else {
                 float h0, l0, h1, l1;
                 split_trunc(pc, h0, l0);
@@ -367,6 +377,13 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
             if constexpr (KIND == BW_HID && u == NU - 1) {
                 if constexpr (n >= 1 && n - 1 < 12) { xh[n - 1] = nh[n - 1]; xl[n - 1] = nl[n - 1]; }
             }
+#ifdef NERF_BWD_KSTEP_FENCE
+            // experiment, off: pin every k-step's epilogue work behind ITS MFMA (left alone, hipcc pairs the MFMAs of two
+            // k-steps and runs both epilogues after them).  The fenced schedule alternates 1 MFMA : 4-7 vector instructions
+            // as written -- and measured 1 % slower per mixed_float16 step: the order is not what keeps the epilogue from
+            // overlapping the matrix pipe (profiles/r3_diagnostic_ab.txt)
+            if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
+#endif
         });
     });
     if constexpr (KIND == BW_XYZ) {      // end of the chain: the last encoding tile's epilogue has no chain to ride on

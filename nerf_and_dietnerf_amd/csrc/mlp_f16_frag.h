@@ -17,7 +17,11 @@ __device__ __forceinline__ void lds_read_frag_asm(f32x4& dst, uint32_t base) {
 }
 template <int N>
 __device__ __forceinline__ void lds_wait_frag_asm(f32x4& reg) {
+#ifdef NERF_DIAG_NO_LDSWAIT    // timing-only diagnostic (wrong results): the fragment is used without waiting for it
+    asm volatile("" : "+a"(reg) : : "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(reg) : "n"(N) : "memory");
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // RNE; v_cvt_pk_f16_f32
