@@ -513,6 +513,10 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             }
     };
 
+#ifndef NERF_ATB_STAGGER
+#define NERF_ATB_STAGGER 1
+#endif
+    const bool late_half = NERF_ATB_STAGGER && W == 256 && __builtin_amdgcn_readfirstlane(wave) >= 4;
     if (steps > 0) {
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q) fetch(R[q], q);
@@ -520,20 +524,36 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         __syncthreads();
         int buf = 0;
         // step st: registers in slot st % NS; unrolled by NS for static register indices (the last round may run past the
-        // end: those steps park zeros)
-        for (long long base_st = 1; base_st < steps; base_st += NS) {
+        // end: those steps park zeros).
+        // Stagger (NERF_ATB_STAGGER): waves w and w + 4 of a 512-thread workgroup share a SIMD and, running the same
+        // program between the same barriers, did their MFMAs together and their staging (vector work) together.  The
+        // second half parks FIRST and computes after -- park writes buffer buf ^ 1, compute reads buffer buf, both orders
+        // are legal between two barriers -- so one partner's MFMAs run beside the other's split / pack / LDS stores
+        // (MI355X_MICROARCH.md, "try a stagger").  Two copies of the whole loop, chosen once per wave: the choice inside
+        // the loop body cost 400 spilled registers.
+        auto main_loop = [&](auto late_c) {
+            for (long long base_st = 1; base_st < steps; base_st += NS) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const long long st = base_st + i;
-                fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(buf);
-                __builtin_amdgcn_sched_barrier(0);
-                park(R[(1 + i) % NS], st, buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
+                for (int i = 0; i < NS; ++i) {
+                    const long long st = base_st + i;
+                    fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (decltype(late_c)::value) {
+                        park(R[(1 + i) % NS], st, buf ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute(buf);
+                    } else {
+                        compute(buf);
+                        __builtin_amdgcn_sched_barrier(0);
+                        park(R[(1 + i) % NS], st, buf ^ 1);
+                    }
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
-        }
+        };
+        if (late_half) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
         compute(buf);
     }
 
@@ -725,6 +745,7 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     };
 
     steps = ms < me ? (me - ms) / 16 : 0;
+    const bool late_half = NERF_ATB_STAGGER && W == 256 && __builtin_amdgcn_readfirstlane(wave) >= 4;
     if (steps > 0) {
         const long long groups = (steps + PB - 1) / PB;
 #pragma unroll
@@ -733,20 +754,30 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         __syncthreads();
         int buf = 0;
         // group st: registers in slot st % NS; unrolled by NS for static register indices.  The last round may run past
-        // the end: those groups park zeros.
-        for (long long base_st = 1; base_st < groups; base_st += NS) {
+        // the end: those groups park zeros.  (Stagger of the SIMD partners: see gemm_atb_h_kernel.)
+        auto main_loop = [&](auto late_c) {
+            for (long long base_st = 1; base_st < groups; base_st += NS) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const long long st = base_st + i;
-                fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(buf);
-                __builtin_amdgcn_sched_barrier(0);
-                park(R[(1 + i) % NS], st, buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
+                for (int i = 0; i < NS; ++i) {
+                    const long long st = base_st + i;
+                    fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (decltype(late_c)::value) {
+                        park(R[(1 + i) % NS], st, buf ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute(buf);
+                    } else {
+                        compute(buf);
+                        __builtin_amdgcn_sched_barrier(0);
+                        park(R[(1 + i) % NS], st, buf ^ 1);
+                    }
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
-        }
+        };
+        if (late_half) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
         compute(buf);
     }
 
