@@ -415,6 +415,12 @@ def main():
                     "frac": (by / seconds / 1e9 / PEAK_HBM_GBS) if by else None, "traffic": by,
                     "traffic_source": "offline rocprofv3 PMC, summed over the kernels of one step (profiles/pmc_traffic.json)",
                     "structural_bytes": algo, "traffic_vs_structural": (by / algo) if by else None,
+                    # half of the step's bytes are WRITES (stash, gradient buffers), and the write path saturates well below
+                    # the 8 TB/s spec: a bare MFMA chain streaming stores out measures 5.0-5.6 TB/s chip-wide
+                    # (tools/microbench/mem_issue_cost, profiles/r3_mem_issue_cost.txt); a float4 copy reads at 6.3 TB/s
+                    "achievable": {"write_GBps": 5300.0, "read_GBps": 6300.0,
+                                   "frac_of_mean": (by / seconds / 1e9 / 5800.0) if by else None,
+                                   "source": "tools/microbench/mem_issue_cost (writes), MI355X_MICROARCH.md (reads)"},
                     "note": "the step is HBM-bound: activations and pre-activation gradients are written once (stash "
                             "forward, backward chain) and read once (weight-gradient GEMMs); structural_bytes counts "
                             "exactly that. SURVEY 8(d)-style algorithmic bytes (rays + weights + moments) are ~20 MB."}
