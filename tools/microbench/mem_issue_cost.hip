@@ -12,7 +12,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-enum { NONE, ST2_V, ST4_V, ST2_S, ST4_S, ST2_V_PLAIN, DMA, LOAD_DSWRITE, LOAD_ONLY };
+enum { NONE, ST2_V, ST4_V, ST2_S, ST4_S, ST2_V_PLAIN, DMA, LOAD_DSWRITE, LOAD_ONLY, SKEL_LDS, SKEL_LDS_DMA, SKEL_FULL, SKEL_EPI, SKEL_EPI_ST, X_NODMA, X_VGPRFRAG, X_NOACCREAD, X_NOWAIT, X_PLAIN6, X_NODMA_PLAIN6, X_VGPRFRAG_NODMA, X_B64_PLAIN6, X_HALFRATE_PLAIN6, X_B32_PLAIN6, X_EARLY_PLAIN6, X_PREVSLOT_PLAIN6, X_VALUFIRST_PLAIN6, X_NOPS, X_PLAIN1, X_PLAIN3, X_SALU6, X_NOLDS_PLAIN6, X_NOLDS_IND6, X_IND6, X_BURST8, X_BURST4 };
 
 template <int KIND, int PER>
 __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const float* in, unsigned long long* cyc, int iters) {
@@ -35,6 +35,15 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
     for (int i = 0; i < 4; ++i) stage[i] = d4;
     unsigned int lds_dst = wave * 4096;
     unsigned int wsoff = wave * 4096 + lane * 16;
+    float ev[3] = {in[1], in[2], in[3]};
+    unsigned int sdummy = 0;
+    float ind[6] = {in[1], in[2], in[3], in[4], in[5], in[6]};
+    unsigned int eh[8];
+    for (int i = 0; i < 8; ++i) eh[i] = lane + i;
+    f32x4 pfq[8], pfq2[8];
+    const unsigned int lane16 = lane * 16;
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(pfq[i]) : "v"(lane16), "n"(0) : "memory");
+    for (int i = 0; i < 8; ++i) pfq2[i] = pfq[i];
     unsigned long long t0, t1;
     __syncthreads();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -42,6 +51,108 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            if (KIND >= SKEL_LDS) {
+                // the fused kernels' skeleton: the A fragment of every MFMA comes from the LDS ring, read 8 MFMAs ahead
+                f32x4& slot = pfq[q];
+                f32x4& refill = pfq[(KIND == X_PREVSLOT_PLAIN6) ? ((q + 7) & 7) : q];
+                if (KIND == X_VALUFIRST_PLAIN6) {       // vector work BEFORE the wait / read / MFMA of this step
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ev[w % 3]) : "v"(eh[5]));
+                }
+                if (KIND == X_EARLY_PLAIN6) {           // MFMA first, then the read, then the vector work
+                    asm volatile("s_waitcnt lgkmcnt(7)" : "+a"(slot) : : "memory");
+                    const h8 aa0 = __builtin_bit_cast(h8, slot);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aa0, b[q & 3], acc, 0, 0, 0);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(pfq[(q + 7) & 7]) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ev[w % 3]) : "v"(eh[5]));
+                    continue;
+                }
+                constexpr bool vfrag = KIND == X_VGPRFRAG || KIND == X_VGPRFRAG_NODMA;
+                if (KIND == X_BURST8 || KIND == X_BURST4) {
+                    // fragment reads in BURSTS (8 or 4 at a time into the other register bank), MFMA + vector work in between
+                    constexpr int B = KIND == X_BURST8 ? 8 : 4;
+                    if ((q % B) == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < B; ++r) {
+                            f32x4& dst = ((it * 8 + q) / B) & 1 ? pfq[r] : pfq2[r];
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+                        }
+                    }
+                    f32x4& cur = ((it * 8 + q) / B) & 1 ? pfq2[q % B] : pfq[q % B];
+                    asm volatile("" : "+a"(cur));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur), b[q & 3], acc, 0, 0, 0);
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ind[w]) : "v"(eh[5]));
+                    continue;
+                }
+                if (KIND == X_NOLDS_PLAIN6 || KIND == X_NOLDS_IND6) {     // no LDS at all: the A operand stays where it is
+                    const h8 aa1 = __builtin_bit_cast(h8, slot);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aa1, b[q & 3], acc, 0, 0, 0);
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) {
+                        if (KIND == X_NOLDS_PLAIN6) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ev[w % 3]) : "v"(eh[5]));
+                        else asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ind[w]) : "v"(eh[5]));
+                    }
+                    continue;
+                }
+                if (KIND == X_NOWAIT || KIND == X_HALFRATE_PLAIN6) asm volatile("" : "+a"(slot) : : "memory");
+                else if (vfrag) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(slot) : : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(7)" : "+a"(slot) : : "memory");
+                const h8 aa = __builtin_bit_cast(h8, slot);
+                if (KIND == X_B64_PLAIN6) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(*(double*)&slot) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+                else if (KIND == X_B32_PLAIN6) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=a"(slot[0]) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+                else if (KIND == X_HALFRATE_PLAIN6 && (q & 1)) asm volatile("" : "+a"(slot));      // a fragment read every second MFMA only
+                else if (vfrag) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(slot) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(refill) : "v"(lane16 + ((it & 3) * 32768u)), "n"(0) : "memory");
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aa, b[q & 3], acc, 0, 0, 0);
+                if (KIND != SKEL_LDS && KIND != X_NODMA && KIND != X_NODMA_PLAIN6 && KIND != X_VGPRFRAG_NODMA && KIND < X_B64_PLAIN6 && (q & 3) == 3) {
+                    const char* src = wsrc + (size_t)(op & 127) * 16384;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(wsoff), "s"(src), "s"(lds_dst + (op & 7) * 16384) : "memory");
+                    ++op;
+                }
+                if (KIND == X_NOPS) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // 24 idle issue cycles, no vector work
+                if (KIND == X_SALU6) {
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sdummy));
+                }
+                if (KIND == X_IND6) {
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ind[w]) : "v"(eh[5]));
+                }
+                if (KIND == X_PLAIN1 || KIND == X_PLAIN3) {
+#pragma unroll
+                    for (int w = 0; w < (KIND == X_PLAIN1 ? 1 : 3); ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ev[w % 3]) : "v"(eh[5]));
+                }
+                if (KIND == X_PLAIN6 || KIND == X_NODMA_PLAIN6 || (KIND >= X_B64_PLAIN6 && KIND < X_VALUFIRST_PLAIN6)) {
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ev[w % 3]) : "v"(eh[5]));
+                }
+                if (KIND == SKEL_EPI || KIND == SKEL_EPI_ST || (KIND >= X_NODMA && KIND <= X_NOWAIT) || KIND == X_VGPRFRAG_NODMA) {
+                    // + the single-pass backward chain's epilogue of one value per MFMA (valu_cost_f16.hip, KIND 20) and,
+                    // SKEL_EPI_ST, its 512-byte D store every fourth MFMA
+                    const int i = q & 1;
+                    if (KIND != X_NOACCREAD) asm volatile("v_accvgpr_read_b32 %0, a201" : "=v"(ev[i]) ::);
+                    asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(eh[i]) : "v"(eh[7]));
+                    asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(eh[i]) : "v"(eh[5]), "v"(eh[6]));
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ev[i]) : "v"(eh[i]));
+                    if (q & 1) {
+                        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(eh[2]) : "v"(ev[0]), "v"(ev[1]));
+                        asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(d2[(q >> 1) & 1]) : "v"(eh[2]), "v"(eh[4]));
+                        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ev[2]) : "v"(ev[0]), "v"(ev[1]));
+                    }
+                    if (KIND == SKEL_EPI_ST && (q & 3) == 3) {
+                        asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(vaddr), "v"(d2) : "memory");
+                        vaddr += 512;
+                    }
+                }
+                if (KIND >= SKEL_FULL && q == 7 && (it & 3) == 3) {      // one chunk = 32 MFMAs: counted wait + barrier
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                continue;
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q & 3], b[q & 3], acc, 0, 0, 0);
             if ((q % PER) == PER - 1) {
                 if (KIND == ST2_V) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(vaddr), "v"(d2) : "memory");
@@ -69,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float s = 0.f;
+    float s = ev[0] + ev[1] + ev[2] + (float)eh[2] + (float)sdummy + ind[0] + ind[1] + ind[2] + ind[3] + ind[4] + ind[5];
     for (int j = 0; j < 16; ++j) s += acc[j];
     for (int i = 0; i < 4; ++i) s += (float)stage[i][0];
     if (s == 12345.678f) ((float*)out)[threadIdx.x] = s;      // keep everything alive without touching the store stream
@@ -119,5 +230,32 @@ int main() {
     BOTH(DMA, "global_load_lds_dwordx4 (LDS-DMA piece)")
     BOTH(LOAD_ONLY, "global_load_dwordx4 to registers")
     BOTH(LOAD_DSWRITE, "global_load_dwordx4 + ds_write_b128")
+    run<SKEL_LDS, 4>("skeleton: + LDS fragment read per MFMA", out, wsrc, in, cyc);
+    run<SKEL_LDS_DMA, 4>("skeleton: + LDS-DMA piece per 4 MFMAs", out, wsrc, in, cyc);
+    run<SKEL_FULL, 4>("skeleton: + vmcnt wait and s_barrier per 32", out, wsrc, in, cyc);
+    run<SKEL_EPI, 4>("skeleton: + the backward epilogue's VALU mix", out, wsrc, in, cyc);
+    run<SKEL_EPI_ST, 4>("skeleton: + its D store per 4 MFMAs", out, wsrc, in, cyc);
+    run<X_NODMA, 4>("  epilogue, no DMA pieces", out, wsrc, in, cyc);
+    run<X_VGPRFRAG, 4>("  epilogue, fragments read into VGPRs", out, wsrc, in, cyc);
+    run<X_VGPRFRAG_NODMA, 4>("  epilogue, VGPR fragments, no DMA", out, wsrc, in, cyc);
+    run<X_NOACCREAD, 4>("  epilogue without v_accvgpr_read", out, wsrc, in, cyc);
+    run<X_NOWAIT, 4>("  epilogue, no lgkmcnt wait", out, wsrc, in, cyc);
+    run<X_PLAIN6, 4>("  six v_mul_f32 instead of the epilogue", out, wsrc, in, cyc);
+    run<X_NODMA_PLAIN6, 4>("  six v_mul_f32, no DMA pieces", out, wsrc, in, cyc);
+    run<X_B64_PLAIN6, 4>("  six v_mul_f32, no DMA, ds_read_b64 per MFMA", out, wsrc, in, cyc);
+    run<X_B32_PLAIN6, 4>("  six v_mul_f32, no DMA, ds_read_b32 per MFMA", out, wsrc, in, cyc);
+    run<X_HALFRATE_PLAIN6, 4>("  six v_mul_f32, no DMA, b128 every 2nd MFMA, no wait", out, wsrc, in, cyc);
+    run<X_PREVSLOT_PLAIN6, 4>("  six v_mul_f32, no DMA, refill the PREVIOUS MFMA's slot", out, wsrc, in, cyc);
+    run<X_EARLY_PLAIN6, 4>("  six v_mul_f32, no DMA, order: MFMA, read (prev slot), VALU", out, wsrc, in, cyc);
+    run<X_VALUFIRST_PLAIN6, 4>("  six v_mul_f32, no DMA, order: VALU, wait, read, MFMA", out, wsrc, in, cyc);
+    run<X_NOPS, 4>("  no vector work, 24 cycles of s_nop per MFMA, no DMA", out, wsrc, in, cyc);
+    run<X_SALU6, 4>("  six s_add_u32 per MFMA, no DMA", out, wsrc, in, cyc);
+    run<X_PLAIN1, 4>("  one v_mul_f32 per MFMA, no DMA", out, wsrc, in, cyc);
+    run<X_PLAIN3, 4>("  three v_mul_f32 per MFMA, no DMA", out, wsrc, in, cyc);
+    run<X_IND6, 4>("  six INDEPENDENT v_mul_f32 per MFMA, LDS reads, no DMA", out, wsrc, in, cyc);
+    run<X_BURST8, 4>("  six independent v_mul_f32, fragment reads in bursts of 8", out, wsrc, in, cyc);
+    run<X_BURST4, 4>("  six independent v_mul_f32, fragment reads in bursts of 4", out, wsrc, in, cyc);
+    run<X_NOLDS_PLAIN6, 4>("  six v_mul_f32 (3 registers), NO LDS reads", out, wsrc, in, cyc);
+    run<X_NOLDS_IND6, 4>("  six independent v_mul_f32, NO LDS reads", out, wsrc, in, cyc);
     return 0;
 }

@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const float* in, unsigne
                 if (KIND == 7) asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(hv[i]) : "v"(hv[(i + 1) & 7]), "v"(hv[(i + 2) & 7]));
                 if (KIND == 8) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(alpha));
                 if (KIND == 9) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(*(double*)&v[(i & 3) * 2]) : "v"(*(double*)&v[((i + 1) & 3) * 2]));
+                if (KIND == 10) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(hv[i]) : "v"(hv[(i + 1) & 7]), "v"(hv[(i + 2) & 7]));
+                if (KIND == 11) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(hv[i]) : "v"(hv[(i + 1) & 7]), "v"(hv[(i + 2) & 7]));
+                if (KIND == 12) asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(hv[i]) : "v"(hv[(i + 1) & 7]));
+                if (KIND == 13) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "v"(v[(i + 2) & 7]));
+                if (KIND == 14) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hv[i]) : "v"(v[i]), "v"(v[(i + 1) & 7]));
+            }
+            // KIND 20: the single-pass backward chain's epilogue of one value per MFMA, as its ISA has it (NV ignored):
+            // accumulator read, LeakyReLU' select from the mask bit, scale; every second MFMA: pack, D pair, running max
+            if (KIND >= 20 && KIND <= 24) {
+                const int i = q & 1;
+                // 22: the accumulator already in an architectural VGPR (no v_accvgpr_read); 23: also no v_pk_mul_f16;
+                // 24: as 22 with LeakyReLU' applied to the packed pair (shift + v_pk_ashrrev_i16 + v_bfi per PAIR)
+                if (KIND == 20 || KIND == 21) asm volatile("v_accvgpr_read_b32 %0, a201" : "=v"(v[i]) ::);
+                if (KIND == 24) {
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(alpha));
+                    if (q & 1) {
+                        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hv[2]) : "v"(v[0]), "v"(v[1]));
+                        asm volatile("v_lshlrev_b32 %0, 7, %1" : "=v"(hv[0]) : "v"(hv[7]));
+                        asm volatile("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(hv[0]) : "v"(hv[0]));
+                        asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(hv[0]) : "v"(hv[5]), "v"(hv[6]));
+                        asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(hv[2]) : "v"(hv[2]), "v"(hv[0]));
+                        asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(hv[3]) : "v"(hv[2]), "v"(hv[4]));
+                        asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(hv[1]) : "v"(hv[2]));
+                    }
+                    continue;
+                }
+                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(hv[i]) : "v"(hv[7]));
+                asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(hv[i]) : "v"(hv[5]), "v"(hv[6]));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(hv[i]));
+                if (q & 1) {
+                    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hv[2]) : "v"(v[0]), "v"(v[1]));
+                    if (KIND == 20 || KIND == 22) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(hv[3]) : "v"(hv[2]), "v"(hv[4]));
+                    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(v[2]) : "v"(v[0]), "v"(v[1]));
+                }
             }
         }
     }
@@ -78,6 +112,14 @@ int main() {
     run<0, 0, 1>("baseline+lds", out, in, cyc);
     RUN3(0, "v_mul_f32") RUN3(1, "v_max_f32") RUN3(2, "v_accvgpr_read") RUN3(3, "v_cvt_f16_f32") RUN3(4, "v_cvt_f32_f16")
     RUN3(5, "v_cvt_pkrtz_f16_f32") RUN3(6, "v_sub_f32") RUN3(7, "v_pack_b32_f16") RUN3(8, "v_mov_b32") RUN3(9, "v_pk_mul_f32")
+    RUN3(10, "v_pk_mul_f16") RUN3(11, "v_bfi_b32") RUN3(12, "v_bfe_i32") RUN3(13, "v_max3_f32 |.|") RUN3(14, "v_cvt_pk_f16_f32")
+    // the single-pass backward chain's epilogue (one value per MFMA) and cheaper formulations of it.  (No "+ lds" rows for
+    // these: this file's LDS reads are compiler-scheduled two MFMAs ahead and their wait lands wherever the asm blocks
+    // leave room -- 42 to 65 cycles with no pattern; the kernels read eight ahead with counted waits.)
+    run<20, 0, 0>("bwd f16 epilogue mix", out, in, cyc);
+    run<21, 0, 0>("  same without v_pk_mul_f16", out, in, cyc);
+    run<22, 0, 0>("  accumulator in a VGPR (no accvgpr_read)", out, in, cyc);
+    run<24, 0, 0>("  VGPR acc, LeakyReLU' on the packed pair", out, in, cyc);
     run<0, 4, 1>("v_mul + lds", out, in, cyc);
     return 0;
 }
