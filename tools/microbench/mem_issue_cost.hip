@@ -1,6 +1,10 @@
 // Microbenchmark: what ONE vector-memory instruction costs a wave that runs a dependent chain of
 // v_mfma_f32_32x32x16_f16 (one wave per SIMD, 256 workgroups of 4 waves): stores of the trainer's shapes in their
 // address forms, and the two ways of feeding the LDS weight ring (LDS-DMA vs load-to-register + ds_write_b128).
+// The SKEL_* / X_* rows rebuild the fused kernels' skeleton (fragment read per MFMA, DMA piece per four, chunk wait + barrier)
+// and add vector work: the chain collapses from 36 to 82 cycles per MFMA once a fragment read sits between every MFMA and
+// the next, and recovers (44) with the reads in bursts of four -- a pattern that did NOT carry over to the kernels
+// (profiles/r3_diagnostic_ab.txt), kept here as measured.
 // Output: cycles per MFMA and the extra cycles per memory instruction over the bare chain (s_memtime of wave 0 of
 // workgroup 0, whole-kernel time beside it).   Build: make -C tools/microbench mem_issue_cost
 #include <hip/hip_runtime.h>
