@@ -16,7 +16,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-enum { NONE, ST2_V, ST4_V, ST2_S, ST4_S, ST2_V_PLAIN, DMA, LOAD_DSWRITE, LOAD_ONLY, SKEL_LDS, SKEL_LDS_DMA, SKEL_FULL, SKEL_EPI, SKEL_EPI_ST, X_NODMA, X_VGPRFRAG, X_NOACCREAD, X_NOWAIT, X_PLAIN6, X_NODMA_PLAIN6, X_VGPRFRAG_NODMA, X_B64_PLAIN6, X_HALFRATE_PLAIN6, X_B32_PLAIN6, X_EARLY_PLAIN6, X_PREVSLOT_PLAIN6, X_VALUFIRST_PLAIN6, X_NOPS, X_PLAIN1, X_PLAIN3, X_SALU6, X_NOLDS_PLAIN6, X_NOLDS_IND6, X_IND6, X_BURST8, X_BURST4 };
+enum { NONE, ST2_V, ST4_V, ST2_S, ST4_S, ST2_V_PLAIN, DMA, LOAD_DSWRITE, LOAD_ONLY, SKEL_LDS, SKEL_LDS_DMA, SKEL_FULL, SKEL_EPI, SKEL_EPI_ST, X_NODMA, X_VGPRFRAG, X_NOACCREAD, X_NOWAIT, X_PLAIN6, X_NODMA_PLAIN6, X_VGPRFRAG_NODMA, X_B64_PLAIN6, X_HALFRATE_PLAIN6, X_B32_PLAIN6, X_EARLY_PLAIN6, X_PREVSLOT_PLAIN6, X_VALUFIRST_PLAIN6, X_NOPS, X_PLAIN1, X_PLAIN3, X_SALU6, X_NOLDS_PLAIN6, X_NOLDS_IND6, X_IND6, X_BURST8, X_BURST4, X_BURST4_DMA, X_BURST4_DMA_ST, X_BURST4_EPI_DMA_ST };
 
 template <int KIND, int PER>
 __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const float* in, unsigned long long* cyc, int iters) {
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
     // this wave's output region: n_ops x 1 KiB, streamed
     const size_t n_ops = (size_t)iters * 8 / PER;
     char* region = out + ((size_t)blockIdx.x * 4 + wave) * n_ops * 1024;
-    constexpr int kLaneBytes = (KIND == ST2_V || KIND == ST2_S || KIND == ST2_V_PLAIN) ? 8 : 16;    // contiguous per wave-instruction
+    constexpr int kLaneBytes = (KIND == ST2_V || KIND == ST2_S || KIND == ST2_V_PLAIN || KIND >= SKEL_EPI_ST) ? 8 : 16;    // contiguous per wave-instruction
     unsigned long long vaddr = (unsigned long long)region + lane * kLaneBytes;     // per-lane 64-bit address (vaddr forms)
     unsigned int voff = lane * kLaneBytes;                                        // per-lane 32-bit offset (saddr forms)
     const char* sbase = region;                                           // wave-uniform base
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
                     continue;
                 }
                 constexpr bool vfrag = KIND == X_VGPRFRAG || KIND == X_VGPRFRAG_NODMA;
-                if (KIND == X_BURST8 || KIND == X_BURST4) {
+                if (KIND == X_BURST8 || KIND >= X_BURST4) {
                     // fragment reads in BURSTS (8 or 4 at a time into the other register bank), MFMA + vector work in between
-                    constexpr int B = KIND == X_BURST8 ? 8 : 4;
+                    constexpr int B = KIND == X_BURST8 ? 8 : 4;      // (every later KIND: bursts of 4)
                     if ((q % B) == 0) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -87,8 +87,30 @@ __global__ __launch_bounds__(256, 1) void k(char* out, const char* wsrc, const f
                     f32x4& cur = ((it * 8 + q) / B) & 1 ? pfq2[q % B] : pfq[q % B];
                     asm volatile("" : "+a"(cur));
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur), b[q & 3], acc, 0, 0, 0);
+                    if (KIND == X_BURST4_EPI_DMA_ST) {      // the backward epilogue's own mix instead of six v_mul
+                        const int i = q & 1;
+                        asm volatile("v_accvgpr_read_b32 %0, a201" : "=v"(ev[i]) ::);
+                        asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(eh[i]) : "v"(eh[7]));
+                        asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(eh[i]) : "v"(eh[5]), "v"(eh[6]));
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ev[i]) : "v"(eh[i]));
+                        if (q & 1) {
+                            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(eh[2]) : "v"(ev[0]), "v"(ev[1]));
+                            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(d2[(q >> 1) & 1]) : "v"(eh[2]), "v"(eh[4]));
+                            asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ev[2]) : "v"(ev[0]), "v"(ev[1]));
+                        }
+                    } else {
 #pragma unroll
-                    for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ind[w]) : "v"(eh[5]));
+                        for (int w = 0; w < 6; ++w) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(ind[w]) : "v"(eh[5]));
+                    }
+                    if (KIND >= X_BURST4_DMA && (q & 3) == 3) {
+                        const char* src = wsrc + (size_t)(op & 127) * 16384;
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(wsoff), "s"(src), "s"(lds_dst + (op & 7) * 16384) : "memory");
+                        ++op;
+                        if (KIND >= X_BURST4_DMA_ST) {
+                            asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(vaddr), "v"(d2) : "memory");
+                            vaddr += 512;
+                        }
+                    }
                     continue;
                 }
                 if (KIND == X_NOLDS_PLAIN6 || KIND == X_NOLDS_IND6) {     // no LDS at all: the A operand stays where it is
@@ -259,6 +281,9 @@ int main() {
     run<X_IND6, 4>("  six INDEPENDENT v_mul_f32 per MFMA, LDS reads, no DMA", out, wsrc, in, cyc);
     run<X_BURST8, 4>("  six independent v_mul_f32, fragment reads in bursts of 8", out, wsrc, in, cyc);
     run<X_BURST4, 4>("  six independent v_mul_f32, fragment reads in bursts of 4", out, wsrc, in, cyc);
+    run<X_BURST4_DMA, 4>("  ... bursts of 4 + a DMA piece per 4 MFMAs", out, wsrc, in, cyc);
+    run<X_BURST4_DMA_ST, 4>("  ... bursts of 4 + DMA piece + 512-byte store per 4 MFMAs", out, wsrc, in, cyc);
+    run<X_BURST4_EPI_DMA_ST, 4>("  backward epilogue mix, bursts of 4 + DMA piece + store per 4", out, wsrc, in, cyc);
     run<X_NOLDS_PLAIN6, 4>("  six v_mul_f32 (3 registers), NO LDS reads", out, wsrc, in, cyc);
     run<X_NOLDS_IND6, 4>("  six independent v_mul_f32, NO LDS reads", out, wsrc, in, cyc);
     return 0;
