@@ -235,14 +235,20 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         // (pk = t * (rho / inv) would save the second select, but a sample whose gradient underflows has inv = 0 and
         // rho / inv = Inf: 0 * Inf poisoned the weight gradients -- measured, reverted)
         pk = acc_v * mask_select(neg, arho_s, rho_s);
+#if !(defined(NERF_DIAG_BWD_EPI) && NERF_DIAG_BWD_EPI == 6)    // 6: timing-only, no running max of the packed operand
         L.mrun = fmaxf(L.mrun, fabsf(pk));
+#endif
         if constexpr ((r & 1) == 0) pc = pk;
         else {
             constexpr int n = 2 * ht + (r >> 3), d = (r & 7) >> 1;
             if constexpr (FAST) {
                 const uint32_t ph = pack_h2(pc, pk);
+#if defined(NERF_DIAG_BWD_EPI) && NERF_DIAG_BWD_EPI == 5    // timing-only: the next operand is NOT rewritten (the value is only kept alive)
+                asm volatile("" : : "v"(ph));
+#else
                 if constexpr (decltype(to_x)::value) xh[n][d] = ph;
                 else nh[n][d] = ph;
+#endif
                 // mixed_float16 policy: D is stored in fp16 (dst points at fp16 rows).  The values carry the loss scale, as
                 // the policy's activation gradients do: an overflow becomes Inf here, NaN in the weight gradient, and the
                 // LossScaleOptimizer logic skips the step and halves the scale.
@@ -280,7 +286,11 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         // epilogue (u == 0) looks for it, whatever the tile count
         constexpr int kOff = (NA - NU % NA) % NA;
         f32x16& acc = accs[(u + kOff) % NA];
+#if defined(NERF_DIAG_BWD_EPI) && NERF_DIAG_BWD_EPI == 4    // timing-only: the epilogue reads a tile finished TWO tiles ago
+        f32x16& prv = accs[(u + kOff + NA - 2) % NA];
+#else
         f32x16& prv = accs[u == 0 ? NA - 1 : (u + kOff + NA - 1) % NA];
+#endif
         static_for<0, NSTEP>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             f32x4 araw[2];
