@@ -14,9 +14,14 @@ oracle (numpy/OpenBLAS restatement of the reference algorithm -- NOT TensorFlow,
 installable here) on a bounded sample of the same workload on the host cores of rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -77,6 +82,108 @@ def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
                       f"{t:.1f} s; CPU restatement of the reference algorithm (not TensorFlow)"}
 
 
+def csrc_sha16():
+    """Hash of the kernel sources the running library was built from (profiles/pmc_traffic.json records the hash its
+    counters were collected on, so a stale traffic figure can say so)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nerf_and_dietnerf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` starts its own ranks.  The driver launches N > 1 through torch.distributed.run (WORLD_SIZE is
+# then set and this block is skipped); a harness that calls `python3 bench.py --gpus 8` the way it calls `--gpus 1` gets
+# the same one-process-per-GPU job: N fresh children of THIS process -- started before it touches torch or the GPU,
+# never a re-exec -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's stdout (the one JSON line) passed
+# through, the other ranks' output on stderr, the worst exit code returned, and the whole group killed when one rank
+# fails or the wall-clock limit (BENCH_LAUNCH_TIMEOUT seconds, default 1500) passes.
+# ---------------------------------------------------------------------------------------------------------------------
+def child_argv(argv):
+    """The command line of one rank: this script with the very same arguments."""
+    return [sys.executable, os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _kill_group(proc, sig):
+    try:
+        os.killpg(proc.pid, sig)          # every rank is its own session leader (start_new_session): pid == pgid
+    except (ProcessLookupError, PermissionError):
+        pass
+
+
+def launch_ranks(cmd, n, timeout_s=1500.0, env=None, out=None, err=None, poll_s=0.1):
+    """Start ``n`` copies of ``cmd`` as ranks 0..n-1 of one node and wait for them.  -> worst exit code (124 = timed out)."""
+    out = out or sys.stdout
+    err = err or sys.stderr
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs, pumps = [], []
+
+    def pump(stream, sink, tag):
+        for line in iter(stream.readline, ""):
+            sink.write(line if tag is None else f"[rank {tag}] {line}")
+            sink.flush()
+        stream.close()
+
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+            p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1,
+                                 start_new_session=True)
+            procs.append(p)
+            for stream, sink, tag in ((p.stdout, out if r == 0 else err, None if r == 0 else r), (p.stderr, err, r)):
+                t = threading.Thread(target=pump, args=(stream, sink, tag), daemon=True)
+                t.start()
+                pumps.append(t)
+        t0 = time.monotonic()
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = max(bad, key=abs)
+                err.write(f"bench.py: rank {codes.index(bad[0])} exited with {bad[0]}; stopping the other ranks\n")
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > timeout_s:
+                rc = 124
+                err.write(f"bench.py: {n}-rank run exceeded {timeout_s:.0f} s; stopping it\n")
+                break
+            time.sleep(poll_s)
+    except BaseException:
+        rc = 130
+        raise
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            _kill_group(p, signal.SIGTERM)
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in live) and time.monotonic() - t1 < 10.0:
+            time.sleep(0.05)
+        for p in live:
+            if p.poll() is None:
+                _kill_group(p, signal.SIGKILL)
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:      # noqa: BLE001
+                pass
+        for t in pumps:
+            t.join(timeout=5)
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +204,11 @@ def main():
                          "(no collective); the printed value is that slab's rays/s x k (an estimate, not a result)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before torch or the GPU is touched in this process)
+        raise SystemExit(launch_ranks(child_argv(sys.argv[1:]), args.gpus,
+                                      float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))))
+
     import torch
     import torch.distributed as dist
 
@@ -104,8 +216,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     # BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box
     backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -333,9 +443,9 @@ def main():
             # BASELINE configs[3]: DietNeRF consistency-render shape (150x150, 55+55, batches of 2048 rays)
             cfg4 = dict(side_run(model, "f16x3", 20, 150, 150, 55, 55, c2w, FOV, batch=2048),
                         workload="150x150, 55 coarse + 55 fine, 2048-ray batches (src/DietNeRF.py:215-218), headline mode")
-            # ... and what DietNeRF does with that image: back-propagate dL/d(image) through NeRF.render, batch by batch
+            # ... and what DietNeRF does with that image: back-propagate dL/d(image) through NeRF.render, batch by batch --
+            # under both policies (the reference can only run it under mixed_float16, src/ExecutionRun.py:220-221)
             model.ctx.set_precision("f16x3")
-            model.compile(5e-4)
             d_img = torch.rand((150 * 150, 3), device="cuda") * 1e-3
             dirs4 = model.ctx.get_rays_directions(150, 150, FOV, torch.as_tensor(c2w, device="cuda")).reshape(-1, 4)
             orig4 = torch.as_tensor(c2w[:, 3], device="cuda").expand(150 * 150, 4).contiguous()
@@ -344,18 +454,29 @@ def main():
                 for b in range(0, 150 * 150, 2048):
                     model.ctx.train_render_gradients(orig4[b:b + 2048], dirs4[b:b + 2048], d_img[b:b + 2048], 55, 55,
                                                      seed=seed, ray_base=b, accumulate=b > 0)
-            consistency_backward(0)
-            sync()
-            t4 = time.perf_counter()
-            for i in range(3):
-                consistency_backward(1 + i)
-            sync()
-            e4 = (time.perf_counter() - t4) / 3
-            model.ctx.train_end()
-            cfg4["render_gradients"] = {"ms_per_image": e4 * 1e3, "value": 150 * 150 / e4, "unit": "rays/s",
-                                        "note": "nerf_train_render_gradients: forward with stash + backward through the "
-                                                "merged 110-sample fine pass and the sampler, 11 batches of 2048 rays "
-                                                "(src/DietNeRF.py:204-222); fp32 policy"}
+
+            def time_consistency(mixed):
+                model.compile(5e-4, mixed_float16=mixed)
+                consistency_backward(0)
+                sync()
+                t4 = time.perf_counter()
+                for i in range(3):
+                    consistency_backward(1 + i)
+                    model.ctx.train_apply()
+                sync()
+                e = (time.perf_counter() - t4) / 3
+                ls = model.ctx.train_loss_scale()
+                model.ctx.train_end()
+                return {"ms_per_image": e * 1e3, "value": 150 * 150 / e, "unit": "rays/s", "steps_applied": ls[1],
+                        "steps_skipped": ls[2]}
+            rg32, rg16 = time_consistency(False), time_consistency(True)
+            cfg4["render_gradients"] = dict(rg32, policy="float32",
+                                            note="nerf_train_render_gradients: forward with stash + backward through the "
+                                                 "merged 110-sample fine pass and the sampler, 11 batches of 2048 rays "
+                                                 "(src/DietNeRF.py:204-222), then nerf_train_apply",
+                                            mixed_float16_policy=dict(rg16, note="the reference's production policy: d_rgb "
+                                                                      "loss-scaled on the device, single-pass fp16 chain, "
+                                                                      "unscaled gradients, one verdict per image"))
             # BASELINE configs[4]: 800x800, 64 coarse + 256 fine, fp16 MLP
             cfg5 = dict(side_run(model, "f16", 3, 800, 800, 64, 256, c2w, FOV),
                         workload="800x800, 64 coarse + 256 fine (fine pass 320 samples), single-pass fp16 MLP mode")
@@ -411,9 +532,15 @@ def main():
         def hbm_view(seconds, key, elem_bytes):
             by = tr_bytes.get(key)
             algo = rows_tr * elems_per_row * elem_bytes * 2.0
-            return {"bound": "hbm", "achieved": (by / seconds / 1e9) if by else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            measured_on = tr_bytes.get("csrc_sha16")
+            return {"bound": "hbm", "bound_status": "priced against HBM, not proven to be bound by it: see bound_evidence",
+                    "achieved": (by / seconds / 1e9) if by else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": (by / seconds / 1e9 / PEAK_HBM_GBS) if by else None, "traffic": by,
                     "traffic_source": "offline rocprofv3 PMC, summed over the kernels of one step (profiles/pmc_traffic.json)",
+                    # the counters were collected on a particular build: say so, and say when the running sources differ
+                    "traffic_measured_on_csrc_sha16": measured_on, "running_csrc_sha16": csrc_sha16(),
+                    "traffic_stale": (measured_on != csrc_sha16()) if measured_on else None,
+                    "bound_evidence": tr_bytes.get("issue_side"),
                     "structural_bytes": algo, "traffic_vs_structural": (by / algo) if by else None,
                     # half of the step's bytes are WRITES (stash, gradient buffers), and the write path saturates well below
                     # the 8 TB/s spec: a bare MFMA chain streaming stores out measures 5.0-5.6 TB/s chip-wide
@@ -421,9 +548,12 @@ def main():
                     "achievable": {"write_GBps": 5300.0, "read_GBps": 6300.0,
                                    "frac_of_mean": (by / seconds / 1e9 / 5800.0) if by else None,
                                    "source": "tools/microbench/mem_issue_cost (writes), MI355X_MICROARCH.md (reads)"},
-                    "note": "the step is HBM-bound: activations and pre-activation gradients are written once (stash "
-                            "forward, backward chain) and read once (weight-gradient GEMMs); structural_bytes counts "
-                            "exactly that. SURVEY 8(d)-style algorithmic bytes (rays + weights + moments) are ~20 MB."}
+                    "note": "the step's traffic: activations and pre-activation gradients are written once (stash forward, "
+                            "backward chain) and read once (weight-gradient GEMMs); structural_bytes counts exactly that. "
+                            "The weight-gradient GEMMs stream at 0.8-0.94 of the achievable read rate; the fused stash / "
+                            "backward kernels write at 0.7-0.8 of the achievable write rate while their waves are also "
+                            "VALU-issue limited (bound_evidence): a mixed bound. SURVEY 8(d)-style algorithmic bytes "
+                            "(rays + weights + moments) are ~20 MB."}
         train = {"metric": "train_step (NeRF.train_step: coarse+fine forward, backward incl. sampler, Adam)",
                  "value": n_tr / e_tr, "unit": "rays/s", "ms_per_step": e_tr * 1e3, "steps": k_tr, "dtype": "f16 (3-pass hi/lo split operands, f32 accumulate; fp32-class results)",
                  "batch_rays": n_tr, "samples": f"{SC} coarse + {SF} fine (fine pass on the new samples only)",
@@ -473,6 +603,52 @@ def main():
                          "bytes_to_host_per_frame": {"rgb_only": total * 12, "six_outputs": total * (12 + (SC + SF) * 28)},
                          "note": "nerf_render_image(NERF_MEM_HOST) into page-locked buffers (nerf_host_alloc): outputs leave on a "
                                  "copy stream behind per-batch events while the next batch computes; never the headline value"}
+
+    # the xyz-only network (n_angles_for_model = 0, src/NeRF.py:248-288; 5 of the 46 shipped configs) beside the
+    # view-direction network: render rate and training step -- reported figures (the -m gpu suite only keeps sanity floors)
+    xyz_only = None
+    if world == 1 and args.rehearse_world <= 1 and not args.quick:
+        xyz_only = {}
+        for na in (2, 0):
+            cx = N.Context(near=NEAR, far=FAR, n_angles=na, precision="f16x3", device=dev_index)
+            cx.load_weights(0, N.glorot_blob(11, n_angles=na))
+            cx.load_weights(1, N.glorot_blob(12, n_angles=na))
+            cx.use_torch_stream()
+            f = lambda sd: cx.render_image(c2w, FOV, H, W, 0, SC, SF, seed=sd, device_out=True, rgb_only=True)   # noqa: E731
+            f(0)
+            sync()
+            tx = time.perf_counter()
+            for i in range(6):
+                f(1 + i)
+            sync()
+            r_render = 6 * total / (time.perf_counter() - tx)
+            steps_ms = {}
+            if not args.no_train:
+                gen = torch.Generator(device="cuda").manual_seed(1)
+                x_o = torch.zeros((4096, 4), device="cuda"); x_o[:, 2] = 1.0; x_o[:, 3] = 1.0
+                x_d = torch.randn((4096, 4), device="cuda", generator=gen) * 0.3; x_d[:, 2] = -1.0; x_d[:, 3] = 0.0
+                x_t = torch.rand((4096, 3), device="cuda", generator=gen)
+                for pol in ("float32", "mixed_float16"):
+                    cx.train_begin(5e-4, mixed_float16=pol == "mixed_float16")
+                    for i in range(3):
+                        cx.train_step(x_o, x_d, x_t, SC, SF, seed=i, want_metrics=False)
+                    sync()
+                    tx = time.perf_counter()
+                    for i in range(15):
+                        cx.train_step(x_o, x_d, x_t, SC, SF, seed=10 + i, want_metrics=False)
+                    sync()
+                    steps_ms[pol] = (time.perf_counter() - tx) / 15 * 1e3
+                    cx.train_end()
+            xyz_only["view_direction_network" if na else "xyz_only_network"] = {
+                "render_rays_per_s": r_render, "train_ms_per_step": steps_ms or None}
+            cx.close()
+        a, b = xyz_only["xyz_only_network"], xyz_only["view_direction_network"]
+        xyz_only["render_rate_vs_view_direction_network"] = a["render_rays_per_s"] / b["render_rays_per_s"]
+        if a["train_ms_per_step"]:
+            xyz_only["train_step_time_vs_view_direction_network"] = {
+                k: a["train_ms_per_step"][k] / b["train_ms_per_step"][k] for k in a["train_ms_per_step"]}
+        xyz_only["note"] = ("256x256, 64 + 128, f16x3 render mode; 4096-ray training steps; the xyz-only network has 12 Dense "
+                            "layers, 6 % more MACs per row and one more layer of stash traffic")
 
     if rank == 0:
         value = total * args.steps / elapsed
@@ -531,6 +707,8 @@ def main():
             out["training"] = train
         if host_boundary is not None:
             out["host_boundary"] = host_boundary
+        if xyz_only is not None:
+            out["xyz_only"] = xyz_only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 3
+#define NERF_ABI_VERSION 4
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
 enum { NERF_MEM_HOST = 0, NERF_MEM_DEVICE = 1 };
@@ -156,6 +156,16 @@ int nerf_comm_destroy(nerf_ctx* ctx);
 int nerf_render_image_sharded(nerf_ctx* ctx, const float* c2w, float field_of_view, int32_t H, int32_t W,
                               int64_t batch, int32_t n_coarse, int32_t n_fine, uint64_t seed,
                               float* rgb /* (H*W,3) */, int mem);
+/* ABI 4: the same assembly for EVERY requested output of NeRF.render_image (src/NeRF.py:239-246) -- one ncclAllGather of
+ * equal padded slabs per non-NULL pointer of `outs`; each destination holds the WHOLE image
+ * ((H*W,3), (H*W,S), (H*W,S,3), (H*W) for depth; S = n_coarse + n_fine, or n_coarse without a fine network) on every
+ * rank.  What the reference's video loop needs per frame is weights and z (depth = sum_s w*z, src/ExecutionRun.py:339-356)
+ * -- or the fused `depth` output alone; its special ray plots take all six (:487).  Host destinations leave on the
+ * ctx's copy stream, one output's copy under the next output's gather (page-locked buffers from nerf_host_alloc move by
+ * DMA).  nerf_render_image_sharded is this call with rgb alone. */
+int nerf_render_image_sharded_outputs(nerf_ctx* ctx, const float* c2w, float field_of_view, int32_t H, int32_t W,
+                                      int64_t batch, int32_t n_coarse, int32_t n_fine, uint64_t seed,
+                                      const nerf_outputs* outs, int mem);
 
 /* ---- status ------------------------------------------------------------------------------ */
 /* Synchronises and returns (then clears) the number of sample rows whose network output was not finite
@@ -206,6 +216,11 @@ int nerf_train_loss_scale(nerf_ctx* ctx, float* loss_scale, int64_t* steps_appli
 int nerf_train_step(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* target_rgb,
                     int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
                     float* metrics, int mem);
+/* ABI 4: Keras' History keeps the per-epoch MEANS of train_step's metrics (model.fit, src/ExecutionRun.py:186-201).  Every
+ * nerf_train_step / nerf_train_gradients adds its loss, psnr_coarse and psnr_fine (the very values `metrics` would receive)
+ * to running sums on the device; this call synchronises, returns the sums and the number of steps since the last read,
+ * and clears them -- a training loop passes metrics = NULL per step (no synchronisation) and reads once per epoch. */
+int nerf_train_read_metric_sums(nerf_ctx* ctx, double* sums /* [3]: loss, psnr_coarse, psnr_fine */, int64_t* steps);
 /* The two halves of a step, for data-parallel training: gradients (kept in the ctx and optionally copied out
  * as blobs), then -- after the caller averaged them over ranks -- the Adam update (NULL = use the ctx's own).
  * mixed_float16 (ABI 3): nerf_train_gradients returns UNSCALED gradients and takes no verdict; nerf_train_apply tests
@@ -224,7 +239,15 @@ int nerf_train_apply(nerf_ctx* ctx, const float* grad_coarse, const float* grad_
  * leaves dL/d(weights) in the ctx's gradient blobs: overwriting them (accumulate = 0) or adding to what
  * nerf_train_gradients left there (accumulate = 1: the reference sums both losses before one Adam step), ready for
  * nerf_train_apply(ctx, NULL, NULL, mem).  The coarse network receives gradient only through the inverse-CDF sampler
- * (none with sampler_gradient = 0).  rgb_out / grad_coarse / grad_fine: optional copies. */
+ * (none with sampler_gradient = 0).  rgb_out / grad_coarse / grad_fine: optional copies.
+ * mixed_float16 (ABI 4; the policy the reference always runs under, src/ExecutionRun.py:220-221): DietNeRF scales the
+ * SUM of ray loss and consistency loss and unscales once (src/DietNeRF.py:142-153,192-202).  Here the caller's d_rgb is
+ * multiplied by the current loss scale ON THE DEVICE, the single-pass fp16 chain runs on it (fp16 gradient buffers that
+ * carry the scale, as in nerf_train_gradients), and the call leaves UNSCALED gradients: stored (accumulate = 0) or added to
+ * the unscaled gradients nerf_train_gradients left (accumulate = 1) -- like with like.  The finiteness flag is reset by
+ * accumulate = 0 (a new gradient computation; gradients that were computed and never applied do not decide this one's
+ * verdict) and COLLECTS over nerf_train_gradients + accumulate = 1 calls; nerf_train_apply takes the one verdict on the
+ * summed blobs: a non-finite d_rgb (or an overflow in the chain) skips the step and halves the scale. */
 int nerf_train_render_gradients(nerf_ctx* ctx, const float* rays_orig, const float* rays_dirs, const float* d_rgb,
                                 int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine,
                                 uint64_t seed, int64_t ray_base, int32_t accumulate, float* rgb_out,

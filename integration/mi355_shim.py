@@ -20,7 +20,7 @@ def keras_leaky_relu_alpha(keras_model):
                      "activation object); pass attach(..., leaky_relu_alpha=net_config['leaky_relu_alpha'])")
 
 
-def attach(model, device=0, precision="fp32", to_tensor=None, context_factory=None, seed_source=None,
+def attach(model, device=0, precision="auto", to_tensor=None, context_factory=None, seed_source=None,
            leaky_relu_alpha=None):
     """model: the reference's NeRF (attributes used: n_pos_enc_dim_xyz, n_pos_enc_view_dir,
     n_angles_for_model, near_boundary, far_boundary, n_render_samples_coarse/_fine, batch_size_render,

@@ -69,6 +69,8 @@ struct TrainState {
     bool mixed = false;
     DevBuf opt;                     // OptState (train_kernels.h): loss scale, verdicts, Adam iteration count -- on the device
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
+    DevBuf macc;                    // running sums of the step metrics (4 doubles: loss, psnr_coarse, psnr_fine, steps)
+    DevBuf gsave[2];                // ... under mixed_float16 with accumulate = 1: the (unscaled) gradients already there
 };
 
 }  // namespace nerf
@@ -301,9 +303,16 @@ struct WgradQueue {
     bool open = false;
 };
 
-void wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
+// floats of partial sums a batched launch needs: the layout loop of wgrad_flush, for the slab count it would choose
+size_t wgrad_batch_floats(const WgradQueue& q, int splits) {
+    size_t off = 0;
+    for (int e = 0; e < q.gemm.n; ++e) off += (size_t)splits * (q.gemm.e[e].Kp + 1) * q.gemm.e[e].Nw;
+    return off;
+}
+
+int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     q.open = false;
-    if (q.gemm.n == 0) return;
+    if (q.gemm.n == 0) return 0;
     int units = 0;
     for (int e = 0; e < q.gemm.n; ++e) units += (q.gemm.e[e].Kp + 255) / 256 * ((q.gemm.e[e].Nw + 255) / 256);
     // one 512-thread workgroup per CU, workgroups dealt round-robin to the 8 XCDs: a multiple of 8 slabs per layer such
@@ -314,6 +323,9 @@ void wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = (rps + 31) / 32 * 32;
     const int splits = (int)((Mp + rps - 1) / rps);
+    // the slab count follows the device's CU count: grow the partial-sum buffer to what THIS launch lays out (a device with
+    // more CUs, a larger batch of layers) instead of trusting the size the per-layer launches were given
+    if (int r = ensure(c, t->partial, wgrad_batch_floats(q, splits) * sizeof(float))) { q.gemm.n = q.red.n = 0; return r; }
     size_t off = 0;
     for (int e = 0; e < q.gemm.n; ++e) {
         GemmAtb& g = q.gemm.e[e];
@@ -327,6 +339,7 @@ void wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     else launch_gemm_atb_h_batch(q.gemm, c->stream, true);
     launch_reduce_grad_batch(q.red, c->stream);
     q.gemm.n = q.red.n = 0;
+    return 0;
 }
 
 void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
@@ -454,7 +467,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         const size_t xyz_off = (size_t)32 * 256;
         const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
         wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(g0 + 8), &wq);
-        wgrad_flush(c, t, wq, Mp);
+        if (int r = wgrad_flush(c, t, wq, Mp)) return r;
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
             launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream, true);
@@ -549,6 +562,10 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     r |= ensure(c, t->d_wext, dc.M * f);
     r |= ensure(c, t->d_zf, (fine ? df.M : 1) * f);
     r |= ensure(c, t->scal, 4 * f);
+    if (!t->macc.p) {
+        r |= ensure(c, t->macc, 4 * sizeof(double));
+        if (!r) HIP_OK(hipMemsetAsync(t->macc.p, 0, 4 * sizeof(double), c->stream));
+    }
     r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
     if (r) return r;
     float* scal = (float*)t->scal.p;
@@ -593,6 +610,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         // skip-step behaviour.)
         launch_unscale_check(t->net[0].grad, fine ? t->net[1].grad : nullptr, t->nblob, (OptState*)t->opt.p, c->stream);
     }
+    launch_metrics_accum(scal, fine, (double*)t->macc.p, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -654,14 +672,39 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     r |= ensure(c, t->d_zm, (fine ? df.M : 1) * f);
     r |= ensure(c, t->zero_rgb, N * 3 * f);
     r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
+    if (t->mixed) {
+        r |= ensure(c, t->d_rgb, N * 3 * f);
+        if (accumulate)
+            for (int w = 0; w < 2; ++w)
+                if (t->net[w].present) r |= ensure(c, t->gsave[w], t->nblob * f);
+    }
     if (r) return r;
     float* Graw = (float*)t->Graw.p;
-    t->acc_grads = accumulate;
+    const bool through_sampler = fine && t->cfg.sampler_gradient != 0;
+    // the networks this call computes gradients for: the fine one through its merged pass, the coarse one through the
+    // sampler (or, without a fine network, through its own rgb)
+    const bool computes[2] = {!fine || through_sampler, fine};
+    if (t->mixed) {
+        // mixed_float16 (src/ExecutionRun.py:220-221; DietNeRF scales the SUM of ray loss and consistency loss and unscales
+        // once, src/DietNeRF.py:142-153,192-202): the caller's d_rgb is multiplied by the current loss scale on the device,
+        // the single-pass chain runs on it (fp16 gradient buffers carrying the scale), and the result is UNSCALED and tested
+        // before it is stored or, with accumulate, added to the unscaled gradients nerf_train_gradients left -- like with like.
+        // The finiteness flag is reset only when this call starts a new gradient computation (accumulate = 0), so with
+        // accumulate = 1 it collects over both calls and nerf_train_apply takes the one verdict.
+        OptState* st = (OptState*)t->opt.p;
+        if (!accumulate) launch_opt_begin(st, c->stream);
+        launch_scale_by_loss_scale(dr, N * 3, st, (float*)t->d_rgb.p, c->stream);
+        dr = (const float*)t->d_rgb.p;
+        if (accumulate)
+            for (int w = 0; w < 2; ++w)
+                if (computes[w] && t->net[w].present)
+                    HIP_OK(hipMemcpyAsync(t->gsave[w].p, t->net[w].grad, t->nblob * f, hipMemcpyDeviceToDevice, c->stream));
+    }
+    t->acc_grads = accumulate && !t->mixed;      // (mixed: the scaled result overwrites, the addition happens after unscaling)
 
     TPass& pc = t->pass[0];
     launch_z_values(c->cfg.near_boundary, c->cfg.far_boundary, N, Sc, uc, seed, ray_base, (float*)pc.z.p, c->stream);
     if (int q = forward_pass(c, t, 0, dc, o, d)) { t->acc_grads = false; return q; }
-    const bool through_sampler = fine && t->cfg.sampler_gradient != 0;
     int q = 0;
     if (fine) {
         TPass& pf = t->pass[1];
@@ -701,6 +744,17 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     }
     t->acc_grads = false;
     if (q) return q;
+    if (t->mixed) {
+        float* g[2]; const float* add[2]; int n = 0;
+        for (int w = 0; w < 2; ++w)
+            if (computes[w] && t->net[w].present) {
+                g[n] = t->net[w].grad;
+                add[n] = accumulate ? (const float*)t->gsave[w].p : nullptr;
+                ++n;
+            }
+        launch_unscale_check(g[0], n > 1 ? g[1] : nullptr, t->nblob, (OptState*)t->opt.p, c->stream, false, add[0],
+                             n > 1 ? add[1] : nullptr);
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -764,7 +818,8 @@ void train_free(nerf_ctx* c) {
         for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
-                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->opt};
+                    &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->opt,
+                    &t->gsave[0], &t->gsave[1], &t->macc};
     for (DevBuf* b : bs) free_buf(*b);
     delete t;
     c->train = nullptr;
@@ -879,6 +934,21 @@ int nerf_train_loss_scale(nerf_ctx* c, float* loss_scale, int64_t* steps_applied
     if (loss_scale) *loss_scale = h.scale;
     if (steps_applied) *steps_applied = h.iterations;
     if (steps_skipped) *steps_skipped = h.skipped;
+    return 0;
+}
+
+int nerf_train_read_metric_sums(nerf_ctx* c, double* sums, int64_t* steps) {
+    ENTER(c);
+    TrainState* t = c->train;
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
+    double h[4] = {0, 0, 0, 0};
+    if (t->macc.p) {
+        HIP_OK(hipMemcpyAsync(h, t->macc.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemsetAsync(t->macc.p, 0, sizeof h, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    if (sums) { sums[0] = h[0]; sums[1] = h[1]; sums[2] = h[2]; }
+    if (steps) *steps = (int64_t)h[3];
     return 0;
 }
 

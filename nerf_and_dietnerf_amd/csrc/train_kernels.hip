@@ -1480,28 +1480,60 @@ void launch_mse(const float* rgb, const float* target, long long N, const OptSta
 }
 
 // LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
-// as one entry of either blob is Inf/NaN (the caller sets it to 1 first).
+// as one entry of either blob is Inf/NaN (the caller sets it to 1 first).  add_a / add_b (nullable): blobs added AFTER the
+// test -- nerf_train_render_gradients(accumulate = 1) under mixed_float16 sums its unscaled gradients onto the unscaled
+// ray-loss gradients of nerf_train_gradients (like with like; the reference sums both losses before one
+// get_scaled_loss / get_unscaled_gradients, src/DietNeRF.py:142-153).
 __global__ void unscale_check_kernel(float* __restrict__ ga, float* __restrict__ gb, size_t n, OptState* __restrict__ st,
-                                     int check_only) {
+                                     int check_only, const float* __restrict__ add_a, const float* __restrict__ add_b) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float inv_scale = check_only ? 1.0f : st->inv_scale;
     bool bad = false;
     if (i < n) {
         const float a = ga[i] * inv_scale;
-        ga[i] = a;
+        ga[i] = add_a ? a + add_a[i] : a;
         bad = !(fabsf(a) <= 3.0e38f);
         if (gb) {
             const float b = gb[i] * inv_scale;
-            gb[i] = b;
+            gb[i] = add_b ? b + add_b[i] : b;
             bad |= !(fabsf(b) <= 3.0e38f);
         }
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) st->finite = 0;
 }
 
-void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStream_t s, bool check_only) {
+void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStream_t s, bool check_only, const float* add_a,
+                          const float* add_b) {
     hipLaunchKernelGGL(unscale_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ga, gb, n, st,
-                       check_only ? 1 : 0);
+                       check_only ? 1 : 0, add_a, add_b);
+}
+
+// Keras' History keeps the per-epoch MEANS of train_step's metrics (src/NeRF.py:169-177, src/ExecutionRun.py:192): the sums
+// are kept on the device (one thread per step), so a training loop reads them once per epoch instead of once per step.
+// scal[0] / scal[1] = this step's coarse / fine MSE (mse_kernel); the values added are exactly what read_metrics hands out.
+__global__ void metrics_accum_kernel(const float* __restrict__ scal, int fine, double* __restrict__ acc) {
+    const float h0 = scal[0], h1 = fine ? scal[1] : 0.f;
+    acc[0] += (double)(fine ? h0 + h1 : h0);
+    acc[1] += (double)(float)(-10.0 * log10((double)h0));
+    acc[2] += fine ? (double)(float)(-10.0 * log10((double)h1)) : 0.0;
+    acc[3] += 1.0;
+}
+
+void launch_metrics_accum(const float* scal, bool fine, double* acc, hipStream_t s) {
+    hipLaunchKernelGGL(metrics_accum_kernel, dim3(1), dim3(1), 0, s, scal, fine ? 1 : 0, acc);
+}
+
+// LossScaleOptimizer.get_scaled_loss for a caller-supplied upstream gradient (nerf_train_render_gradients under
+// mixed_float16): out = in * st->scale, the scale read on the device (the host never knows the current value).
+__global__ void scale_by_loss_scale_kernel(const float* __restrict__ in, long long n, const OptState* __restrict__ st,
+                                           float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * st->scale;
+}
+
+void launch_scale_by_loss_scale(const float* in, long long n, const OptState* st, float* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scale_by_loss_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, st, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -80,19 +80,33 @@ def prepare_ds(batch_size: int, c2w_matrices: Sequence, images: Sequence, fov: f
 def fit(model, ds: RayDataset, epochs: int = 1, steps_per_epoch: Optional[int] = None, group=None,
         log_every: int = 0) -> List[Dict[str, float]]:
     """``model.fit(ds, epochs=...)`` for a compiled nerf_and_dietnerf_amd.NeRF: one train_step per batch.
-    Returns one dict of epoch-mean metrics per epoch (what Keras' History holds)."""
+    Returns one dict of epoch-mean metrics per epoch (what Keras' History holds, src/ExecutionRun.py:186-201).
+
+    The loop never waits for a step: ``train_step(..., want_metrics=False)`` only enqueues, the library adds every step's
+    loss / psnr_coarse / psnr_fine to running sums on the device, and the sums are read once per epoch (and every
+    ``log_every`` steps when a progress line is asked for) -- so an epoch runs at the step rate ``bench.py`` reports."""
+    ctx = model.ctx
+    ctx.train_read_metric_sums()                     # start from clean sums
     history = []
     for _ in range(epochs):
         sums: Dict[str, float] = {}
         n = 0
+
+        def collect():
+            part, steps = ctx.train_read_metric_sums()
+            for k, v in part.items():
+                sums[k] = sums.get(k, 0.0) + v
+            return part, steps
+
         for i, batch in enumerate(ds):
             if steps_per_epoch is not None and i >= steps_per_epoch:
                 break
-            m = model.train_step(batch, group=group)
-            for k, v in m.items():
-                sums[k] = sums.get(k, 0.0) + v
+            model.train_step(batch, group=group, want_metrics=False)
             n += 1
             if log_every and n % log_every == 0:
-                print(f"step {n}: " + ", ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)
+                part, steps = collect()
+                print(f"step {n}: " + ", ".join(f"{k} {v / max(steps, 1):.4f}" for k, v in part.items()) +
+                      f" (mean of the last {steps} steps)", flush=True)
+        collect()
         history.append({k: v / max(n, 1) for k, v in sums.items()})
     return history

@@ -39,7 +39,10 @@ N_RAYS_IN_BATCH_TRAIN = "n_rays_in_batch_train"
 N_COORDINATES = 3
 N_COLOR_CHANNELS = 3
 
-_PRECISIONS = {"fp32": NERF_PRECISION_FP32, "f16x3": NERF_PRECISION_F16X3, "f16": _lib.NERF_PRECISION_F16}
+# "auto": render in f16x3 (fp32-class results at 3x the exact-fp32 rate), watch the library's non-finite counter, and fall
+# back to exact fp32 for a weight set whose activations leave the fp16 range (Context._auto_call)
+_PRECISIONS = {"fp32": NERF_PRECISION_FP32, "f16x3": NERF_PRECISION_F16X3, "f16": _lib.NERF_PRECISION_F16,
+               "auto": NERF_PRECISION_F16X3}
 
 
 # --------------------------------------------------------------------------------------------
@@ -68,39 +71,71 @@ class _PinnedPool:
     """Page-locked output buffers for host-memory calls (include/nerf_mi355.h: nerf_host_alloc).  The reference returns
     fresh tensors from every call (src/NeRF.py:239-246); so does this: a block is handed out again only after every numpy
     reference to its previous use is gone.  Pinning costs ~0.2 ms per MB, hence the reuse; at most ``keep_bytes`` of free
-    blocks are kept."""
-    MIN_BYTES = 256 << 10       # smaller outputs are ordinary numpy arrays
-    GRAIN = 2 << 20
+    blocks are kept.
 
-    def __init__(self, keep_bytes: int = 4 << 30):
+    Page-locked memory cannot be swapped, so the pool is BOUNDED: live (handed-out) plus free blocks never exceed
+    ``budget_bytes``.  A request that does not fit first releases free blocks; if it still does not fit -- a caller that keeps
+    hundreds of frames alive -- or if nerf_host_alloc itself fails, ``take`` returns None and the caller falls back to an
+    ordinary pageable ``np.empty`` (the C side accepts any host memory; only the copy/compute overlap is lost)."""
+    MIN_BYTES = 256 << 10       # smaller outputs are ordinary numpy arrays
+    GRAIN = 2 << 20             # blocks of 8 MiB and more are rounded up to this ...
+    SMALL_GRAIN = 128 << 10     # ... smaller ones (an rgb frame: 786 KB at 256 x 256) to this
+
+    def __init__(self, keep_bytes: int = 4 << 30, budget_bytes: int = 8 << 30):
         import threading
         self.free: List[Tuple[int, int]] = []        # (cap, ptr)
         self.keep_bytes, self.free_bytes = keep_bytes, 0
+        self.budget_bytes, self.live_bytes = budget_bytes, 0
+        self.fallbacks = 0                           # requests served from pageable memory instead
         # re-entrant: a garbage collection inside take() may run a dead block's __del__ -> _give_back on this same thread
         self.lock = threading.RLock()
 
-    def take(self, shape) -> np.ndarray:
+    def _grain(self, nbytes: int) -> int:
+        return self.GRAIN if nbytes >= (8 << 20) else self.SMALL_GRAIN
+
+    def take(self, shape) -> Optional[np.ndarray]:
         n = int(np.prod(shape, dtype=np.int64))
         nbytes = 4 * n
         lib = _lib.load()
+        release: List[int] = []
         with self.lock:
             best = None
             for i, (cap, _) in enumerate(self.free):
-                if nbytes <= cap <= nbytes + nbytes // 4 + self.GRAIN and (best is None or cap < self.free[best][0]):
+                if nbytes <= cap <= nbytes + nbytes // 4 + self._grain(nbytes) and (best is None or cap < self.free[best][0]):
                     best = i
             if best is not None:
                 cap, ptr = self.free.pop(best)
                 self.free_bytes -= cap
             else:
-                cap, ptr = -(-nbytes // self.GRAIN) * self.GRAIN, None
+                g = self._grain(nbytes)
+                cap, ptr = -(-nbytes // g) * g, None
+                # make room: free blocks go first, then the request is refused
+                while self.live_bytes + self.free_bytes + cap > self.budget_bytes and self.free:
+                    fcap, fptr = self.free.pop()
+                    self.free_bytes -= fcap
+                    release.append(fptr)
+                if self.live_bytes + self.free_bytes + cap > self.budget_bytes:
+                    cap = 0
+            if cap:
+                self.live_bytes += cap
+        for fptr in release:
+            lib.nerf_host_free(C.c_void_p(fptr))
+        if not cap:
+            self.fallbacks += 1
+            return None
         if ptr is None:
             out = C.c_void_p()
-            _lib.check(lib.nerf_host_alloc(cap, C.byref(out)))
+            if lib.nerf_host_alloc(cap, C.byref(out)) != 0 or not out.value:      # the host cannot pin more: pageable
+                with self.lock:
+                    self.live_bytes -= cap
+                    self.fallbacks += 1
+                return None
             ptr = out.value
         return np.asarray(_PinnedBlock(self, ptr, cap, n)).reshape(tuple(shape))
 
     def _give_back(self, ptr: int, cap: int) -> None:
         with self.lock:
+            self.live_bytes -= cap
             if self.free_bytes + cap <= self.keep_bytes:
                 self.free.append((cap, ptr))
                 self.free_bytes += cap
@@ -155,7 +190,9 @@ class _Arrays:
             self.keep.append(t)
             return t, t.data_ptr()
         nbytes = 4 * int(np.prod(shape, dtype=np.int64))
-        a = _pinned.take(shape) if nbytes >= _PinnedPool.MIN_BYTES else np.empty(tuple(shape), np.float32)
+        a = _pinned.take(shape) if nbytes >= _PinnedPool.MIN_BYTES else None
+        if a is None:                # small output, pinned budget exhausted or pinning failed: pageable memory
+            a = np.empty(tuple(shape), np.float32)
         self.keep.append(a)
         return a, a.ctypes.data
 
@@ -164,7 +201,10 @@ class Context:
     """One nerf_ctx: one GPU, one stream, both networks' weights, a scratch arena."""
 
     def __init__(self, *, n_pos_enc_xyz=5, n_pos_enc_dir=4, n_angles=2, hidden_dim=256, last_hidden_dim=128,
-                 leaky_relu_alpha=0.05, near=2.0, far=6.0, precision="fp32", device=0):
+                 leaky_relu_alpha=0.05, near=2.0, far=6.0, precision="auto", device=0):
+        """``precision``: "auto" (default: f16x3 with the exact-fp32 fallback below), "fp32" (exact fp32 MFMA: the parity
+        mode), "f16x3" (3-pass split-fp16 MFMA, fp32-class results while |activations| < 65504), "f16" (single-pass fp16:
+        the numerics class of the reference's mixed_float16 policy)."""
         self.lib = _lib.load()
         if n_angles not in (0, 1, 2):
             raise Exception(f"{N_ANGLES_FOR_MODEL} should be 1 or 2.")   # src/UtilsCV.py:138
@@ -177,6 +217,10 @@ class Context:
         self.loaded = [False, False]
         self._stream = None
         self.comm_world = 0          # ranks of this ctx's in-library communicator (0 = none)
+        self.precision = precision
+        self._auto_fp32 = False      # "auto": this weight set overflowed fp16 once -> exact fp32 until the weights change
+        self._auto_unchecked = False  # "auto": device-resident calls since the last look at the counter
+        self.auto_fallbacks = 0      # "auto": calls that were re-rendered in exact fp32
 
     def close(self):
         if getattr(self, "h", None):
@@ -202,15 +246,60 @@ class Context:
             blob = np.ascontiguousarray(np.asarray(weights, np.float32).ravel())
         _lib.check(self.lib.nerf_load_weights(self.h, which, blob.ctypes.data, blob.size))
         self.loaded[which] = True
+        self._auto_new_weights()
 
     def set_bounds(self, near: float, far: float) -> None:
         _lib.check(self.lib.nerf_ctx_set_bounds(self.h, near, far))
         self.cfg.near_boundary, self.cfg.far_boundary = near, far
 
     def set_precision(self, precision: str) -> None:
-        """"fp32" (exact fp32 MFMA) or "f16x3" (3-pass split-fp16 MFMA, fp32 accumulate)."""
+        """"auto", "fp32" (exact fp32 MFMA), "f16x3" (3-pass split-fp16 MFMA, fp32 accumulate) or "f16"."""
         _lib.check(self.lib.nerf_ctx_set_precision(self.h, _PRECISIONS[precision]))
         self.cfg.precision = _PRECISIONS[precision]
+        self.precision, self._auto_fp32, self._auto_unchecked = precision, False, False
+
+    # ---- precision="auto": f16x3 by default, exact fp32 for a weight set that needs it ----
+    def _auto_new_weights(self) -> None:
+        """The fallback is per weight set (src/NeRF.py:190-246 renders whatever the model holds): new weights try f16x3 again."""
+        if self.precision == "auto" and self._auto_fp32:
+            _lib.check(self.lib.nerf_ctx_set_precision(self.h, NERF_PRECISION_F16X3))
+            self.cfg.precision, self._auto_fp32 = NERF_PRECISION_F16X3, False
+
+    def _auto_to_fp32(self) -> None:
+        _lib.check(self.lib.nerf_ctx_set_precision(self.h, NERF_PRECISION_FP32))
+        self.cfg.precision, self._auto_fp32, self._auto_unchecked = NERF_PRECISION_FP32, True, False
+
+    def _auto_call(self, call, mem):
+        """Run ``call`` (one path function that evaluates a network).  Under precision="auto" a host-memory call -- which
+        is synchronous on return anyway -- then reads the library's non-finite counter (a device counter the fused kernels
+        add to: one 8-byte copy, no extra synchronisation); a non-zero count means activations left the fp16 range in the
+        f16x3 kernels, so the call is repeated in exact fp32 (same draws: same seed) and the context stays there until
+        its weights change.  Device-resident calls are asynchronous and are NOT checked one by one (that would drain the
+        queue per call): ``auto_check()`` looks at the counter when the caller synchronises (video.render_video does)."""
+        out = call()
+        if self.precision != "auto" or self._auto_fp32:
+            return out
+        if mem != NERF_MEM_HOST:
+            self._auto_unchecked = True
+            return out
+        if self.read_nonfinite() > 0:
+            self._auto_to_fp32()
+            self.auto_fallbacks += 1
+            out = call()
+        self._auto_unchecked = False
+        return out
+
+    def auto_check(self) -> bool:
+        """precision="auto" after device-resident (asynchronous) calls: synchronise, read the non-finite counter and, if it
+        is non-zero, switch to exact fp32 for this weight set.  True = the caller should render those calls again."""
+        if self.precision != "auto" or self._auto_fp32 or not self._auto_unchecked:
+            return False
+        self._auto_unchecked = False
+        if self.read_nonfinite() > 0:
+            self._auto_to_fp32()
+            self.auto_fallbacks += 1
+            return True
+        return False
 
     def synchronize(self) -> None:
         _lib.check(self.lib.nerf_ctx_synchronize(self.h))
@@ -256,20 +345,37 @@ class Context:
         self.comm_world = 0
         _lib.check(self.lib.nerf_comm_destroy(self.h))
 
-    def render_image_sharded(self, c2w, fov, h, w, batch, n_c, n_f, seed=0, device_out=False):
-        """This rank renders its slab, ONE ncclAllGather inside the library assembles (h,w,3) on every rank."""
+    def render_image_sharded(self, c2w, fov, h, w, batch, n_c, n_f, seed=0, device_out=False, outputs=None,
+                             want_depth=False):
+        """This rank renders its slab; ONE ncclAllGather per requested output inside the library assembles the whole image
+        on every rank.  ``outputs=None``: rgb alone -> (h,w,3) (nerf_render_image_sharded).  ``outputs="all"``: the
+        6-tuple of NeRF.render_image (+ depth with ``want_depth``); ``outputs="rgb_depth"``: (rgb, depth), what the video
+        loop needs per frame (src/ExecutionRun.py:339-356) -- through nerf_render_image_sharded_outputs (ABI 4)."""
         c2w_h = np.ascontiguousarray(np.asarray(c2w, np.float32))
         if device_out:
             import torch
-            out = torch.empty((h, w, 3), dtype=torch.float32, device=torch.device("cuda", self.cfg.device))
-            self._arrays(out)                    # device result => enqueue on torch's current stream
-            ptr, mem = out.data_ptr(), NERF_MEM_DEVICE
+            arr = self._arrays(torch.empty(1, device=torch.device("cuda", self.cfg.device)))   # torch's current stream
         else:
-            out = np.empty((h, w, 3), np.float32)
-            ptr, mem = out.ctypes.data, NERF_MEM_HOST
-        _lib.check(self.lib.nerf_render_image_sharded(self.h, c2w_h.ctypes.data, float(fov), h, w, batch, n_c, n_f, seed,
-                                                      ptr, mem))
-        return out
+            arr = self._arrays()
+        if outputs is None:
+            out, ptr = arr.out((h, w, 3))
+            _lib.check(self.lib.nerf_render_image_sharded(self.h, c2w_h.ctypes.data, float(fov), h, w, batch or 0, n_c, n_f,
+                                                          seed, ptr, arr.mem))
+            return out
+        fine = n_f > 0 and self.loaded[NERF_NET_FINE]
+        s = n_c + n_f if fine else n_c
+        if outputs == "rgb_depth":
+            rgb, p0 = arr.out((h, w, 3))
+            d, p6 = arr.out((h, w))
+            o, res = NerfOutputs(p0, None, None, None, None, None, p6), (rgb, d)
+        elif outputs == "all":
+            o, res = self._outputs(arr, h * w, s, want_depth, (h, w))
+            res = res if want_depth else res[:6]
+        else:
+            raise ValueError('outputs must be None, "all" or "rgb_depth"')
+        _lib.check(self.lib.nerf_render_image_sharded_outputs(self.h, c2w_h.ctypes.data, float(fov), h, w, batch or 0, n_c,
+                                                              n_f if fine else 0, seed, C.byref(o), arr.mem))
+        return res
 
     # ---- training (NeRF.train_step, src/NeRF.py:136-178) ----
     def train_begin(self, learning_rate: float, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7,
@@ -287,6 +393,17 @@ class Context:
         s, a, k = C.c_float(), C.c_int64(), C.c_int64()
         _lib.check(self.lib.nerf_train_loss_scale(self.h, C.byref(s), C.byref(a), C.byref(k)))
         return float(s.value), int(a.value), int(k.value)
+
+    def train_read_metric_sums(self) -> Tuple[Dict[str, float], int]:
+        """Sums of the step metrics since the last read and the number of steps they cover (kept on the device; this
+        synchronises and clears them): what a training loop needs for Keras' per-epoch means without reading metrics
+        every step (nerf_train_read_metric_sums, ABI 4)."""
+        sums, steps = (C.c_double * 3)(), C.c_int64()
+        _lib.check(self.lib.nerf_train_read_metric_sums(self.h, sums, C.byref(steps)))
+        out = {"loss": float(sums[0]), "psnr_coarse": float(sums[1])}
+        if self.loaded[1]:
+            out["psnr_fine"] = float(sums[2])
+        return out, int(steps.value)
 
     def train_end(self) -> None:
         _lib.check(self.lib.nerf_train_end(self.h))
@@ -309,6 +426,7 @@ class Context:
         m = (C.c_float * 3)()
         _lib.check(self.lib.nerf_train_step(self.h, po, pd, pt, n, n_c, n_f, uc, uf, seed,
                                             C.cast(m, C.c_void_p) if want_metrics else None, arr.mem))
+        self._auto_new_weights()
         return _metrics(m, n_f > 0 and self.loaded[1]) if want_metrics else None
 
     def train_gradients(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0):
@@ -342,6 +460,7 @@ class Context:
         arr = self._arrays(grad_coarse, grad_fine)
         n = self.blob_size()
         _lib.check(self.lib.nerf_train_apply(self.h, arr.inp(grad_coarse, (n,)), arr.inp(grad_fine, (n,)), arr.mem))
+        self._auto_new_weights()
 
     def train_get_gradients(self, which: int) -> np.ndarray:
         """The gradient blob the ctx holds now (after a data-parallel ``train_step``: the all-reduced mean)."""
@@ -433,9 +552,11 @@ class Context:
         arr = self._arrays(xyz, view_dirs)
         m = int(xyz.shape[0])
         if self.cfg.n_angles == 0:                      # xyz-only network: no direction input (UtilsNRF.py:229-234)
-            out, p = arr.out((m, 4))
-            _lib.check(self.lib.nerf_model_predict(self.h, which, arr.inp(xyz, (m, 3)), None, m, p, arr.mem))
-            return out
+            def run0():
+                out, p = arr.out((m, 4))
+                _lib.check(self.lib.nerf_model_predict(self.h, which, arr.inp(xyz, (m, 3)), None, m, p, arr.mem))
+                return out
+            return self._auto_call(run0, arr.mem)
         if self.cfg.n_angles == 1 and tuple(view_dirs.shape) == (m, 2):
             # the reference hands (x, z) to the n_angles == 1 network (src/UtilsCV.py:134-135); the
             # library takes full directions and ignores y through zero-packed weights
@@ -446,9 +567,12 @@ class Context:
                 v = np.asarray(view_dirs, np.float32)
                 view_dirs = np.stack([v[:, 0], np.zeros(m, np.float32), v[:, 1]], axis=1)
         px, pv = arr.inp(xyz, (m, 3)), arr.inp(view_dirs, (m, 3))
-        out, p = arr.out((m, 4))
-        _lib.check(self.lib.nerf_model_predict(self.h, which, px, pv, m, p, arr.mem))
-        return out
+
+        def run():
+            out, p = arr.out((m, 4))
+            _lib.check(self.lib.nerf_model_predict(self.h, which, px, pv, m, p, arr.mem))
+            return out
+        return self._auto_call(run, arr.mem)
 
     def ray_marching(self, model_output, z_values):
         arr = self._arrays(model_output, z_values)
@@ -463,10 +587,13 @@ class Context:
         arr = self._arrays(rays_orig, rays_dirs, z_values)
         n, s = tuple(z_values.shape)
         po, pd, pz = arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4)), arr.inp(z_values, (n, s))
-        o, res = self._outputs(arr, n, s, False)
-        o.z = None
-        _lib.check(self.lib.nerf_render_rays(self.h, which, po, pd, pz, n, s, C.byref(o), arr.mem))
-        return res[:5]
+
+        def run():
+            o, res = self._outputs(arr, n, s, False)
+            o.z = None
+            _lib.check(self.lib.nerf_render_rays(self.h, which, po, pd, pz, n, s, C.byref(o), arr.mem))
+            return res[:5]
+        return self._auto_call(run, arr.mem)
 
     def render(self, rays_orig, rays_dirs, n_c, n_f, u_coarse=None, u_fine=None, seed=0, ray_base=0,
                want_depth=False):
@@ -477,10 +604,13 @@ class Context:
         po, pd = arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4))
         puc = arr.inp(u_coarse, (n, n_c))
         puf = arr.inp(u_fine, (n, n_f)) if fine else None
-        o, res = self._outputs(arr, n, s, want_depth)
-        _lib.check(self.lib.nerf_render(self.h, po, pd, n, n_c, n_f if fine else 0, puc, puf, seed, ray_base,
-                                        C.byref(o), arr.mem))
-        return res if want_depth else res[:6]
+
+        def run():
+            o, res = self._outputs(arr, n, s, want_depth)
+            _lib.check(self.lib.nerf_render(self.h, po, pd, n, n_c, n_f if fine else 0, puc, puf, seed, ray_base,
+                                            C.byref(o), arr.mem))
+            return res if want_depth else res[:6]
+        return self._auto_call(run, arr.mem)
 
     def render_image(self, c2w, fov, h, w, batch, n_c, n_f, u_coarse=None, u_fine=None, seed=0, ray_begin=0,
                      ray_count=0, want_depth=False, device_out=False, rgb_only=False):
@@ -500,16 +630,19 @@ class Context:
         whole = ray_count <= 0
         n = total if whole else ray_count
         lead = (h, w) if whole else (n,)
-        if rgb_only:
-            rgb, p0 = arr.out(lead + (3,))
-            d, p6 = arr.out(lead) if want_depth else (None, None)
-            o, res = NerfOutputs(p0, None, None, None, None, None, p6), (rgb, None, None, None, None, None, d)
-        else:
-            o, res = self._outputs(arr, n, s, want_depth, lead)
-        _lib.check(self.lib.nerf_render_image(self.h, c2w_h.ctypes.data, float(fov), h, w, 0 if whole else ray_begin,
-                                              0 if whole else ray_count, batch or 0, n_c, n_f if fine else 0, puc,
-                                              puf, seed, C.byref(o), arr.mem))
-        return res if want_depth else res[:6]
+
+        def run():
+            if rgb_only:
+                rgb, p0 = arr.out(lead + (3,))
+                d, p6 = arr.out(lead) if want_depth else (None, None)
+                o, res = NerfOutputs(p0, None, None, None, None, None, p6), (rgb, None, None, None, None, None, d)
+            else:
+                o, res = self._outputs(arr, n, s, want_depth, lead)
+            _lib.check(self.lib.nerf_render_image(self.h, c2w_h.ctypes.data, float(fov), h, w, 0 if whole else ray_begin,
+                                                  0 if whole else ray_count, batch or 0, n_c, n_f if fine else 0, puc,
+                                                  puf, seed, C.byref(o), arr.mem))
+            return res if want_depth else res[:6]
+        return self._auto_call(run, arr.mem)
 
 
 def _metrics(m, fine: bool) -> Dict[str, float]:
@@ -534,7 +667,7 @@ class NeRF:
     """Mirror of the reference model class (src/NeRF.py:22-246): render path and train_step."""
 
     def __init__(self, net_config: Dict, render_config: Dict, near_boundary: float, far_boundary: float,
-                 device: int = 0, precision: str = "fp32"):
+                 device: int = 0, precision: str = "auto"):
         self.ctx = Context(n_pos_enc_xyz=net_config[N_POS_ENC_DIM_XYZ], n_pos_enc_dir=net_config[N_POS_ENC_VIEW_DIR],
                            n_angles=net_config[N_ANGLES_FOR_MODEL], hidden_dim=net_config[HIDDEN_LAYER_DIM],
                            last_hidden_dim=net_config[LAST_HIDDEN_LAYER_DIM],
@@ -588,8 +721,11 @@ class NeRF:
         self._train_calls = 0
         self._mixed = bool(mixed_float16)
 
-    def train_step(self, data, *, u_coarse=None, u_fine=None, seed=None, group=None) -> Dict[str, float]:
+    def train_step(self, data, *, u_coarse=None, u_fine=None, seed=None, group=None,
+                   want_metrics: bool = True) -> Optional[Dict[str, float]]:
         """``data`` = (rays_orig (N,4), rays_dirs (N,4), real_rgb (N,3)) -> {"loss", "psnr_coarse"[, "psnr_fine"]}.
+        ``want_metrics=False`` does not wait for the step (the metrics still enter the device-side sums that
+        ``ctx.train_read_metric_sums()`` hands out: dataset.fit reads them once per epoch).
 
         Under an initialised torch.distributed ``group`` every rank passes its own shard of the batch; the
         gradient blobs are averaged with one all-reduce each before the identical Adam update: inside the library
@@ -606,7 +742,7 @@ class NeRF:
         world = dist_world(group)
         if world == 1 or self.ctx.comm_world == world:
             return self.ctx.train_step(rays_orig, rays_dirs, real_rgb, self.n_render_samples_coarse, n_f, u_coarse,
-                                       u_fine, seed)
+                                       u_fine, seed, want_metrics)
         if self.ctx.comm_world:
             raise RuntimeError(f"the context's communicator has {self.ctx.comm_world} ranks, the group {world}")
         from .sharding import allreduce_mean
@@ -615,7 +751,7 @@ class NeRF:
         gc = allreduce_mean(gc, group, self.ctx.cfg.device)
         gf = allreduce_mean(gf, group, self.ctx.cfg.device) if gf is not None else None
         self.ctx.train_apply(gc, gf)
-        return metrics
+        return metrics if want_metrics else None
 
     def get_weights(self):
         """(coarse blob, fine blob | None), Keras ``get_weights()`` order."""

@@ -219,7 +219,10 @@ def render_video(model, c2w_matrices: Sequence[np.ndarray], field_of_view: float
 
     Frame f uses seed ``seed + f`` (the reference draws fresh jitter for every frame).  With
     ``shard_frames`` under an initialised torch.distributed group, rank r renders frames r, r+P, ... and
-    every rank receives all frames (one all-gather at the end); otherwise each frame is rendered locally.
+    every rank receives all frames (one all-gather at the end).  Without it, a context that has joined an in-library
+    communicator (``ctx.comm_init*``, world > 1) shards WITHIN each frame from C: every rank renders its ray slab and
+    nerf_render_image_sharded_outputs all-gathers rgb and depth (two collectives per frame); otherwise each frame is
+    rendered locally.
     """
     import torch
     mats = np.asarray(c2w_matrices, dtype=np.float32)
@@ -229,12 +232,29 @@ def render_video(model, c2w_matrices: Sequence[np.ndarray], field_of_view: float
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = list(range(rank, n_frames, world))
-    rgbs, deps = [], []
-    for f in mine:                                   # enqueue only: no host sync inside the loop
-        out = model.render_image(mats[f], field_of_view, h, w, seed=seed + f, device_out=True, rgb_only=True,
-                                 want_depth=True)
-        rgbs.append(out[0])
-        deps.append(out[6])
+    ctx = getattr(model, "ctx", None)
+    within = not shard_frames and ctx is not None and getattr(ctx, "comm_world", 0) > 1
+
+    def enqueue():
+        rgbs, deps = [], []
+        for f in mine:                                   # enqueue only: no host sync inside the loop
+            if within:
+                n_f = model.n_render_samples_fine if model.model_fine else 0
+                r, d = ctx.render_image_sharded(mats[f], field_of_view, h, w, 0, model.n_render_samples_coarse, n_f,
+                                                seed=seed + f, device_out=True, outputs="rgb_depth")
+            else:
+                out = model.render_image(mats[f], field_of_view, h, w, seed=seed + f, device_out=True, rgb_only=True,
+                                         want_depth=True)
+                r, d = out[0], out[6]
+            rgbs.append(r)
+            deps.append(d)
+        return rgbs, deps
+
+    rgbs, deps = enqueue()
+    # precision="auto": the frames were enqueued in f16x3 without looking at the non-finite counter; one look now, and a
+    # weight set that left the fp16 range renders the video again in exact fp32 (same seeds)
+    if not within and ctx is not None and hasattr(ctx, "auto_check") and ctx.auto_check():
+        rgbs, deps = enqueue()
     # a rank with no frame of its own still takes part in the gather with an empty slab
     dev = torch.device("cuda", model.ctx.cfg.device) if torch.cuda.is_available() else torch.device("cpu")
     rgb = torch.stack(rgbs) if rgbs else torch.empty((0, h, w, 3), device=dev)

