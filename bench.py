@@ -131,6 +131,12 @@ def launch_ranks(cmd, n, timeout_s=1500.0, env=None, out=None, err=None, poll_s=
 
     def pump(stream, sink, tag):
         for line in iter(stream.readline, ""):
+            if tag is None and not line.lstrip().startswith("{"):
+                # rank 0's stdout carries the ONE JSON line; anything else a library prints there (gloo's connection
+                # banner) goes to stderr so that stdout stays machine-readable
+                err.write(f"[rank 0] {line}")
+                err.flush()
+                continue
             sink.write(line if tag is None else f"[rank {tag}] {line}")
             sink.flush()
         stream.close()
