@@ -18,7 +18,18 @@
 #ifndef NERF_2T_PE_LADDER
 #define NERF_2T_PE_LADDER 1     // positional encodings by angle doubling (nerf_device.h::sin_ladder_fp16_modes)
 #endif
+// Packed-pair epilogue of the 256-wide layers (round 4): a pair of accumulator registers is converted to an fp16 pair
+// FIRST (v_cvt_pk_f16_f32), then bias, alpha and max act on the pair (v_pk_add_f16, v_pk_mul_f16, v_pk_max_f16) -- 1.5
+// plain vector instructions per value instead of 3, and what Keras computes under mixed_float16 (Dense output cast to
+// fp16, BiasAdd and LeakyReLU in fp16; src/NeRF.py:309-310 under src/ExecutionRun.py:220-221).  The oracle's emulation
+// rounds where this rounds (oracle.mlp_forward_fp16(..., packed_epilogue=True)).  0 = the fp32 epilogue of rounds 2-3.
+#ifndef NERF_2T_PACKED_EPI
+#define NERF_2T_PACKED_EPI 1
+#endif
 namespace nerf {
+
+constexpr int kLdsBias16 = kLdsTotal;                 // fp16 copy of the biases of layers 0..7 (natural order), built at kernel start
+constexpr int kLdsTotal2T = kLdsTotal + 8 * 256 * 2;
 
 namespace {
 
@@ -32,7 +43,7 @@ __device__ __forceinline__ uint32_t park(uint32_t v) {          // VGPR -> AGPR 
 // protocol are those of layer_body_h<.., FAST = true> (mlp_f16x3.hip); every k-step issues the two sets' MFMAs on
 // the one fragment it fetched.
 template <int BODY, bool PENDING>
-__device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t cb_h, int bias_off_bytes, float alpha,
+__device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t cb_h, uint32_t b16h, int bias_off_bytes, float alpha,
                                               f32x16 (&accs)[2][4], frag4 (&xh)[2][16], uint32_t (&nh)[2][14][4],
                                               const frag4 (&peh)[2][3], const frag4 (&dh)[2][2], float (&orgb)[2][3],
                                               float (&sigma_raw)[2]) {
@@ -64,6 +75,35 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
         asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(v), "v"(av));
         return y;
     };
+#if NERF_2T_PACKED_EPI
+    // registers (r, r + 1) of a finished tile -> LeakyReLU(fp16(acc) + fp16(bias)) as one packed fp16 pair
+    const uint32_t alpha2 = pack_h2(alpha, alpha);
+    auto act_pair = [&](float v0, float v1, uint32_t bias2) -> uint32_t {
+        const uint32_t pk = pack_h2(v0, v1);                                  // v_cvt_pk_f16_f32 (RNE)
+        uint32_t t, q, y;
+        asm("v_pk_add_f16 %0, %1, %2" : "=v"(t) : "v"(pk), "v"(bias2));
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(q) : "v"(t), "v"(alpha2));
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(y) : "v"(t), "v"(q));
+        return y;
+    };
+    // fp16 bias pairs of registers 4g .. 4g+3 (lane half h) of tile t of the layer whose fp32 bias block starts at
+    // bias_off_bytes: .x = registers (4g, 4g+1), .y = (4g+2, 4g+3)
+    // (b16h = kLdsBias16 + h * 8, an opaque VGPR like cb_h; + the layer's block + tile + group as immediate offsets)
+    auto bias_pairs = [&](int tile_off64, int g) -> uint2 {
+        extern __shared__ __attribute__((aligned(16))) char smem_[];
+        return *reinterpret_cast<const uint2*>(smem_ + (b16h + (uint32_t)(bias_off_bytes / 2)) + tile_off64 + g * 16);
+    };
+    uint2 bq2;
+    (void)bq2;
+    auto put_pair = [&](auto sc, auto utc, auto rc, uint32_t ph, auto to_x) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int ut = decltype(utc)::value;
+        constexpr int r = decltype(rc)::value;
+        constexpr int n = 2 * ut + (r >> 3), d = (r & 7) >> 1;
+        if constexpr (decltype(to_x)::value) xh[s][n][d] = ph;
+        else nh[s][n][d] = park(ph);
+    };
+#endif
     // Unlike the one-tile kernel the bias is NOT preloaded as C-in: that keeps a third accumulator live per set (32
     // AGPRs for the two sets) and this kernel has none to spare.  A tile's chain starts from zero and its epilogue
     // adds the bias: four floats (registers 4g .. 4g+3, the same for both sets) fetched per four k-steps.
@@ -81,6 +121,7 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
     };
 
     float ycarry[2] = {0.f, 0.f};
+    (void)ycarry; (void)store_pair;
     f32x4 wr0, wr1, wr2;      // rgb head weights of the four features being finished (BODY_LAST)
     (void)wr0; (void)wr1; (void)wr2;
     static_for<0, NU>([&](auto uc) {
@@ -135,8 +176,14 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
                 }
             });
             // bias of the registers this k-step (and the next ones) finish
+#if NERF_2T_PACKED_EPI
+            if constexpr (kPend && (n & 1) == 0) bq2 = bias_pairs(-64, n >> 1);                  // previous layer's tile 7
+            else if constexpr (kPrevS && !kXc && (n & 3) == 0) bq2 = bias_pairs(et * 64, n >> 2);
+            else if constexpr (kXc && (n & 3) == 0) bq = lds_read4(cb_h + bias_off_bytes + et * 128 + (n >> 2) * 32);
+#else
             if constexpr (kPend && (n & 1) == 0) bq = lds_read4(cb_h + bias_off_bytes - 128 + (n >> 1) * 32);   // previous layer's tile 7
             else if constexpr (kPrevS && (n & 3) == 0) bq = lds_read4(cb_h + bias_off_bytes + et * 128 + (n >> 2) * 32);
+#endif
             // rgb head weights for registers n..n+3 of the tile being finished (same for both sets)
             if constexpr (kXc && (n & 3) == 0) {
                 wr0 = lds_read4(cb_h + (kHConstWrgb + 0 * 128 + et * 32 + (n >> 2) * 8) * 4);
@@ -146,6 +193,23 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
             static_for<0, 2>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 f32x16& prv = accs[s][(u + 3) & 3];
+#if NERF_2T_PACKED_EPI
+                if constexpr (kPend) {
+                    constexpr int er = 2 * n;
+                    put_pair(sc, std::integral_constant<int, 7>{}, std::integral_constant<int, er>{},
+                             act_pair(prv[er], prv[er + 1], (n & 1) ? bq2.y : bq2.x), std::true_type{});
+                } else if constexpr (kPrevS && !kXc) {
+                    if constexpr ((n & 1) == 1)
+                        put_pair(sc, std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{},
+                                 act_pair(prv[n - 1], prv[n], (n & 2) ? bq2.y : bq2.x), std::false_type{});
+                } else if constexpr (kXc) {
+                    const float y = act(prv[n] + bq[n & 3]);          // layer 8 feeds the fp32 rgb head: fp32 epilogue
+                    orgb[s][0] = fmaf(wr0[n & 3], y, orgb[s][0]);
+                    orgb[s][1] = fmaf(wr1[n & 3], y, orgb[s][1]);
+                    orgb[s][2] = fmaf(wr2[n & 3], y, orgb[s][2]);
+                    asm volatile("" : "+v"(orgb[s][0]), "+v"(orgb[s][1]), "+v"(orgb[s][2]));
+                }
+#else
                 if constexpr (kPend) {
                     constexpr int er = 2 * n;
                     const float y0 = act(prv[er] + bq[er & 3]), y1 = act(prv[er + 1] + bq[(er & 3) + 1]);
@@ -163,6 +227,7 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
                     } else if constexpr ((n & 1) == 0) ycarry[s] = y;
                     else store_pair(sc, std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, ycarry[s], y, std::false_type{});
                 }
+#endif
                 if constexpr (u == 0 && PENDING) {
                     if constexpr (n == 8) { xh[s][12] = frag4{nh[s][12][0], nh[s][12][1], nh[s][12][2], nh[s][12][3]}; }
                     if constexpr (n == 9) { xh[s][13] = frag4{nh[s][13][0], nh[s][13][1], nh[s][13][2], nh[s][13][3]}; }
@@ -170,10 +235,17 @@ __device__ __forceinline__ void layer_body_2t(Pipe& p, uint32_t lane16, uint32_t
                 if constexpr (BODY == BODY_PE && u > 0 && n == 0) {
                     static_for<0, 8>([&](auto pc) {
                         constexpr int r = 2 * decltype(pc)::value;
+#if NERF_2T_PACKED_EPI
+                        const uint2 b2 = bias_pairs((u - 1) * 64, r >> 2);
+                        const uint32_t ph = act_pair(prv[r], prv[r + 1], (r & 2) ? b2.y : b2.x);
+                        if constexpr (u - 1 <= 5) put_pair(sc, std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, ph, std::true_type{});
+                        else put_pair(sc, std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, ph, std::false_type{});
+#else
                         const f32x4 b4 = lds_read4(cb_h + bias_off_bytes + (u - 1) * 128 + (r >> 2) * 32);
                         const float z0 = act(prv[r] + b4[r & 3]), z1 = act(prv[r + 1] + b4[(r & 3) + 1]);
                         if constexpr (u - 1 <= 5) store_pair(sc, std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::true_type{});
                         else store_pair(sc, std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::false_type{});
+#endif
                     });
                 }
                 if constexpr ((BODY == BODY_HID || BODY == BODY_SKIP) && u == NU - 1) {
@@ -213,13 +285,25 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_2t_kernel(const MlpArgs a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     const uint32_t lane16 = kLdsRing + lane * 16;
-    const uint32_t cb_h = kLdsConst + h * 16;
+    // The constant block sits above 128 KiB of ring: with cb_h a visible expression hipcc folds kLdsConst into every
+    // constant-block address, none of which then fits the 16-bit offset field of a ds_read -- it materialises one base
+    // VGPR per distinct address (30+ registers, hoisted out of the tile loop) and, at this kernel's register limit, spills
+    // them to scratch (reloaded behind `s_waitcnt vmcnt(0)`, i.e. behind the whole DMA queue).  Opaque base + immediate
+    // offsets instead.
+    uint32_t cb_h = kLdsConst + h * 16;
+    asm volatile("" : "+v"(cb_h));
+    uint32_t b16h = kLdsBias16 + h * 8;            // fp16 bias pairs of this lane half (packed epilogue)
+    asm volatile("" : "+v"(b16h));
 
     const long long ntiles = (a.M + 255) / 256;
     if ((long long)blockIdx.x >= ntiles) return;
 
     for (int i = tid; i < kHConstFloats / 4; i += 256)
         reinterpret_cast<f32x4*>(smem + kLdsConst)[i] = reinterpret_cast<const f32x4*>(a.wconst)[i];
+#if NERF_2T_PACKED_EPI
+    for (int i = tid; i < 8 * 256; i += 256)       // fp16 biases of layers 0..7 (RNE), same natural order as the fp32 block
+        reinterpret_cast<_Float16*>(smem + kLdsBias16)[i] = (_Float16)a.wconst[kHConstBias + i];
+#endif
 
     Pipe p;
     p.ck = 0;
@@ -315,15 +399,15 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_2t_kernel(const MlpArgs a) {
             orgb[s][0] = orgb[s][1] = orgb[s][2] = 0.f;
         }
 
-        layer_body_2t<BODY_PE, false>(p, lane16, cb_h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
+        layer_body_2t<BODY_PE, false>(p, lane16, cb_h, b16h, (kHConstBias + 0 * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             if (l == 4)
-                layer_body_2t<BODY_SKIP, true>(p, lane16, cb_h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
+                layer_body_2t<BODY_SKIP, true>(p, lane16, cb_h, b16h, (kHConstBias + 4 * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
             else
-                layer_body_2t<BODY_HID, true>(p, lane16, cb_h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
+                layer_body_2t<BODY_HID, true>(p, lane16, cb_h, b16h, (kHConstBias + l * 256) * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
         }
-        layer_body_2t<BODY_LAST, true>(p, lane16, cb_h, kHConstBias8 * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
+        layer_body_2t<BODY_LAST, true>(p, lane16, cb_h, b16h, kHConstBias8 * 4, a.alpha, accs, xh, nh, peh, dh, orgb, sigma_raw);
 
         // Both sets' results are finished BEFORE any divergent code, and the divergent part is flat (one store region, one
         // counter region).  hipcc (ROCm 7.2) was caught restoring a VGPR it had saved around a nested divergent region
@@ -365,12 +449,12 @@ void launch_mlp_f16_2t(const MlpArgs& a, int num_cus, hipStream_t stream) {
     if (a.M <= 0) return;
     const long long ntiles = (a.M + 255) / 256;
     const int grid = (int)(ntiles < (long long)num_cus ? ntiles : (long long)num_cus);
-    hipLaunchKernelGGL(mlp_f16_2t_kernel, dim3(grid), dim3(256), kLdsTotal, stream, a);
+    hipLaunchKernelGGL(mlp_f16_2t_kernel, dim3(grid), dim3(256), kLdsTotal2T, stream, a);
 }
 
 void mlp_f16_2t_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_f16_2t_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal2T);
 }
 
 }  // namespace nerf

@@ -315,25 +315,46 @@ def mlp_forward(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.nda
 
 
 def mlp_forward_fp16(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: np.ndarray,
-                     dir_enc: np.ndarray, alpha: float = 0.05) -> np.ndarray:
+                     dir_enc: np.ndarray, alpha: float = 0.05, packed_epilogue: bool = False) -> np.ndarray:
     """Emulation of the library's NERF_PRECISION_F16 mode (the numerics class of the reference's production
     mixed_float16 policy, src/ExecutionRun.py:220-221; not TensorFlow's exact op order): operands of every
-    256-wide contraction -- weights and layer inputs -- rounded to fp16 (RNE), products accumulated in fp32 on top of
-    the fp32 bias, LeakyReLU in fp32, activations rounded to fp16 between layers; the 128 -> 3 rgb head in fp32 on
-    the unrounded last hidden layer."""
+    256-wide contraction -- weights and layer inputs -- rounded to fp16 (RNE), products accumulated in fp32; the
+    128 -> 3 rgb head in fp32 on the unrounded last hidden layer.
+
+    packed_epilogue = False (the trainer's stash forward and the one-tile render kernel, csrc/mlp_f16x3.hip FAST):
+    fp32 bias as the accumulator's start value, LeakyReLU in fp32, activations rounded to fp16 between layers.
+    packed_epilogue = True (the two-tile render kernel, csrc/mlp_f16_2t.hip, round 4): layers 0..7 round where Keras'
+    mixed_float16 Dense rounds -- the fp32 sum is cast to fp16 FIRST (v_cvt_pk_f16_f32), then the fp16 bias is added
+    (v_pk_add_f16: one rounding), then LeakyReLU in fp16 with alpha rounded to fp16 (v_pk_mul_f16, v_pk_max_f16);
+    layer 8 (which feeds the fp32 head) and the sigma head keep the fp32 epilogue."""
     q = lambda a: np.asarray(a, F32).astype(np.float16).astype(F32)
+    if packed_epilogue:
+        a16 = np.float16(alpha)
+
+        def dense(x, k, b):
+            y = (x @ q(k)).astype(np.float16)                                       # cast of the fp32 accumulator
+            y = (y.astype(np.float64) + np.asarray(b, F32).astype(np.float16).astype(np.float64)).astype(np.float16)
+            z = (y.astype(F32) * F32(a16)).astype(np.float16)                       # fp16 x fp16 is exact in fp32
+            return np.maximum(y, z).astype(F32)
+    else:
+        dense = lambda x, k, b: q(leaky_relu(x @ q(k) + b, alpha))                 # noqa: E731
     xq, dq = q(xyz_enc), q(dir_enc)
-    h = q(leaky_relu(xq @ q(layers[0][0]) + layers[0][1], alpha))
+    h = dense(xq, *layers[0])
     for k, b in layers[1:4]:
-        h = q(leaky_relu(h @ q(k) + b, alpha))
-    h = q(leaky_relu(np.concatenate([xq, h], axis=-1) @ q(layers[4][0]) + layers[4][1], alpha))
+        h = dense(h, k, b)
+    h = dense(np.concatenate([xq, h], axis=-1), *layers[4])
     for k, b in layers[5:8]:
-        h = q(leaky_relu(h @ q(k) + b, alpha))
+        h = dense(h, k, b)
     hd = np.concatenate([h, dq], axis=-1)
     h8 = leaky_relu(hd @ q(layers[8][0]) + layers[8][1], alpha)          # stays fp32 for the VALU head
     rgb = h8 @ layers[9][0] + layers[9][1]
     sigma = hd @ q(layers[10][0]) + layers[10][1]
     return np.concatenate([rgb, sigma], axis=-1).astype(F32)
+
+
+def mlp_forward_fp16_render(layers, xyz_enc, dir_enc, alpha: float = 0.05) -> np.ndarray:
+    """mlp_forward_fp16 as the single-pass RENDER kernel of the view-direction network computes it (mlp_f16_2t.hip)."""
+    return mlp_forward_fp16(layers, xyz_enc, dir_enc, alpha, packed_epilogue=True)
 
 
 def model_predict(layers, xyz: np.ndarray, view_dirs: np.ndarray, n_pos_enc_xyz: int = 5,
