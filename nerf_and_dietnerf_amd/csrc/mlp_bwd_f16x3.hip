@@ -418,7 +418,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     const uint32_t lane16 = kLdsRing + lane * 16;
-    const uint32_t cb_h = G::LdsConst + h * 16;
+    uint32_t cb_h = G::LdsConst + h * 16;
+    asm volatile("" : "+v"(cb_h));      // opaque base: immediate ds_read offsets instead of one address VGPR per constant (see mlp_f16_2t.hip)
 
     const long long ntiles = a.Mp / 128;
     if ((long long)blockIdx.x >= ntiles) return;

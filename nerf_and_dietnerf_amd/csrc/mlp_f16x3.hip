@@ -336,7 +336,10 @@ __device__ __forceinline__ void mlp_f16_body(const MlpArgs& a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     const uint32_t lane16 = kLdsRing + lane * 16;
-    const uint32_t cb_h = kLdsConst + h * 16;
+    // opaque to the compiler: with the constant visible, hipcc folds kLdsConst (128 KiB, beyond a ds_read's 16-bit offset
+    // field) into every constant-block address and keeps one base VGPR per distinct address (see mlp_f16_2t.hip)
+    uint32_t cb_h = kLdsConst + h * 16;
+    asm volatile("" : "+v"(cb_h));
 
     const long long ntiles = (a.M + 127) / 128;
     if ((long long)blockIdx.x >= ntiles) return;
