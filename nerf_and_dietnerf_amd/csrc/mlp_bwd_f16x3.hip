@@ -225,7 +225,7 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
         // pair, see ratio_h2: bfe + bfi + mul per value)
         const int neg = mask_ones<mask_bit(ht, r)>(mk[ht >> 1]);
         float pk;
-        if constexpr (!FAST) {
+        if constexpr (!FAST && !kPair16) {
             const float t = acc_v * mask_select(neg, ainv_s, inv_s);
             if constexpr ((r & 3) == 0) q0 = t;
             else if constexpr ((r & 3) == 1) q1 = t;
@@ -267,6 +267,18 @@ __device__ __forceinline__ void bwd_body(Pipe& p, uint32_t lane16, float alpha, 
                 const uint32_t ph = pack_h2(h0, h1), pl = pack_h2(l0, l1);
                 if constexpr (decltype(to_x)::value) { xh[n][d] = ph; xl[n][d] = pl; }
                 else { nh[n][d] = ph; nl[n][d] = pl; }
+                // pair16 gradient buffers (nerf_kernels.h::kPair16): D is stored as this very operand pair -- the row's power-of-
+                // two scale stays on it, its inverse goes to rs_ptr once per row and buffer -- in the slot of its fp32 value:
+                // {hi01, hi23, lo01, lo23} per four features.  No true-scale value is formed at all (a select and a multiply
+                // per value less than the fp32 buffers needed).
+                if constexpr (kPair16) {
+                    if constexpr ((r & 3) == 1) { q0 = __uint_as_float(ph); q1 = __uint_as_float(pl); }
+                    else {
+                        frag4 o;
+                        o[0] = __float_as_uint(q0); o[1] = ph; o[2] = __float_as_uint(q1); o[3] = pl;
+                        stream_store(reinterpret_cast<frag4*>(dst + 32 * (32 * ht + 8 * (r >> 2))), o);
+                    }
+                }
             }
         }
     };
@@ -489,7 +501,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                 if constexpr (FAST)
                     stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_ptr[NMQ - 1]) + off128 + 32 * (32 * t + 16 * s + 8 * g)),
                                  make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3])));
-                else
+                else if constexpr (!kPair16)
                     stream_store(reinterpret_cast<f32x4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s + 8 * g)), o);
             }
         }
@@ -517,7 +529,19 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
                 nh[n][e >> 1] = pack_h2(h0, h1);
                 nl[n][e >> 1] = pack_h2(l0, l1);
             }
+            if constexpr (!FAST && kPair16) {      // G9 in pair16 form: the operand fragments are its rows (scale sig, row factor 1 / sig)
+                const int t = n >> 1, s = n & 1;
+                stream_store(reinterpret_cast<frag4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s)), frag4{nh[n][0], nh[n][1], nl[n][0], nl[n][1]});
+                stream_store(reinterpret_cast<frag4*>(a.d_ptr[NMQ - 1] + off128 + 32 * (32 * t + 16 * s + 8)), frag4{nh[n][2], nh[n][3], nl[n][2], nl[n][3]});
+            }
         }
+        // row factor of a pair16 gradient buffer: the upper half of a power of two's fp32 bits (one 2-byte store per row)
+        auto store_rs = [&](int buf, float r) {
+            if constexpr (!FAST && kPair16) {
+                if (h == 0) a.rs_ptr[buf][m] = (uint16_t)(__float_as_uint(r) >> 16);
+            }
+        };
+        store_rs(NMQ - 1, L.inv_sig);
         {   // the sigma head's rank-1 term rides as a 9th k-step: element 0 of lane half 0 = d_sigma
             float h0, l0;
             const float ds = XYZ ? 0.f : graw[3];      // xyz-only: this k-step multiplies zero weights
@@ -541,10 +565,13 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         frag4 mk_prev = mq[1], mk_cur = mq[1];
         bwd_body<BW_HEAD, 0, false, FAST>(p, lane16, alpha, L, false, d_prev, d_cur, nullptr, mk_prev, mk_cur, 0, accs, xh, xl,
                                     nh, nl);
+        int l_cur = XYZ ? 8 : 7;           // index of the buffer d_cur points into
         auto rotate = [&](int l_out) {
             // the per-lane scale state and the mask queue (mq[1] is always the mask of the operand just produced)
             L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
             L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
+            store_rs(l_cur, L.inv_sig);     // the body that just ended packed its outputs with rho: true D = packed * inv / rho
+            l_cur = l_out;
             mk_prev = mk_cur;
 #pragma unroll
             for (int i = 1; i < NMQ - 1; ++i) mq[i] = mq[i + 1];
@@ -575,6 +602,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         }
         L.inv_prev = L.inv_sig; L.rho_prev = L.rho;
         L.inv_sig = L.inv_sig * pow2_inverse(L.rho);
+        store_rs(0, L.inv_sig);
         if constexpr (DX) {
             bwd_body<BW_XYZ, 2, true, FAST>(p, lane16, alpha, L, true, d_cur, nullptr, dxb, mk_cur, mk_cur, NMQ - 1, accs, xh, xl, nh, nl);
         } else {
@@ -587,17 +615,24 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int bit = mask_bit(7, r + e);
-                    const float v = last[r + e] * (((mk_cur[3] >> bit) & 1u) ? alpha : 1.0f) * L.inv_prev;
+                    // pair16: in the scale of D0's other tiles (rho of the last body); true D = that * inv_sig
+                    const float v = last[r + e] * (((mk_cur[3] >> bit) & 1u) ? alpha : 1.0f) * (!FAST && kPair16 ? L.rho_prev : L.inv_prev);
                     o[e] = v;
                     tmax = fmaxf(tmax, fabsf(v));
                 }
-                if constexpr (FAST)
+                if constexpr (!FAST && kPair16) {
+                    float h0, l0, h1, l1, h2_, l2, h3, l3;
+                    split_trunc(o[0], h0, l0); split_trunc(o[1], h1, l1); split_trunc(o[2], h2_, l2); split_trunc(o[3], h3, l3);
+                    stream_store(reinterpret_cast<frag4*>(d_cur + 32 * (32 * 7 + 8 * (r >> 2))),
+                                 frag4{pack_h2(h0, h1), pack_h2(h2_, h3), pack_h2(l0, l1), pack_h2(l2, l3)});
+                } else if constexpr (FAST)
                     stream_store(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(d_cur) + 32 * (32 * 7 + 8 * (r >> 2))),
                                  make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], o[3])));
                 else
                     stream_store(reinterpret_cast<f32x4*>(d_cur + 32 * (32 * 7 + 8 * (r >> 2))), o);
             }
             // max|D0| of this sample: the already packed part (in the next operand's scale) and the flushed tile
+            if constexpr (!FAST && kPair16) tmax *= L.inv_sig;
             tmax = fmaxf(tmax, L.mrun * L.inv_sig);
             lds_gmax_update<FAST>(NMQ - 1, __float_as_uint(max_with_other_half(tmax)));
         }

@@ -108,6 +108,17 @@ void mlp_f16_2t_set_attributes();
 // mlp_bwd_f16x3.hip -- the trainer's fused data-gradient chain (the stash forward's counterpart)
 constexpr size_t kBwdStreamBytes = size_t(73) * 32 * kQuadBytes;   // transposed-weight stream incl. the encoding tiles (73 chunks: the xyz-only network's)
 constexpr int kBwdXyzLd = 64;                                      // floats per row of an encoding-gradient buffer
+// "pair16" gradient buffers of the fused float32-policy trainer (default on; -DNERF_PAIR16=0 builds the fp32 buffers of
+// rounds 2-3 back for A/B runs): the backward chain stores every pre-activation gradient as the fp16 (hi, lo) pair it
+// packs as the next MFMA operand anyway, in the value's fp32 slot -- {hi01, hi23, lo01, lo23} per four consecutive
+// features of a row -- with the chain's per-row power-of-two scale still on it (its inverse is stored per row,
+// MlpBwdArgs::rs_ptr), and the weight-gradient GEMM (gemm_atb_p, train_kernels.hip) stages that operand with byte permutes
+// and one packed multiply instead of scaling and splitting fp32 rows on the fly.  The chain no longer forms the
+// true-scale value at all (a select and a multiply per value less).
+#ifndef NERF_PAIR16
+#define NERF_PAIR16 1
+#endif
+constexpr bool kPair16 = NERF_PAIR16 != 0;
 struct MlpBwdArgs {
     const void* wstream;     // backward operand stream of one network (build_bwd_gather / launch_repack_bwd)
     const float* wconst;     // the forward kernel's constant block (rgb head weights are read from it)
@@ -116,6 +127,8 @@ struct MlpBwdArgs {
     float* d_ptr[10];        // d_ptr[l], l = 0..7: (Mp, 256) gradient w.r.t. layer l's pre-activation; d_ptr[8]: G9 (Mp, 128)
                              // xyz-only network: d_ptr[8] = (Mp, 256) of its extra layer, d_ptr[9] = (Mp, 128) of the last one
     float* dx_ptr[2];        // dx variant: (Mp, 64) gradient w.r.t. the xyz encoding through layer 4 / through layer 0
+    uint16_t* rs_ptr[10];    // kPair16 (3-pass kernels): per buffer d_ptr[l] and row the power of two r with true D = stored D' * r,
+                             // as the upper half of r's fp32 bits
     unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k); xyz-only
                              // network: 10 groups, group 0 = d_ptr[9], group k = d_ptr[9 - k]
     long long Mp;            // rows, multiple of 128

@@ -42,6 +42,7 @@ struct TPass {                      // activations of one pass, kept from forwar
     // fused backward: LeakyReLU' bit records of layers 0..8 (32 B per row and layer, written by the stash forward),
     // the pre-activation gradients D[0..7] (Mp x 256) and G9 = D[8] (Mp x 128), the two encoding-gradient parts
     DevBuf masks, D[10], dxa, dxb;     // D[8], D[9]: see MlpBwdArgs::d_ptr (the xyz-only network has ten gradient buffers)
+    DevBuf rs;                         // pair16 gradient buffers (float32 policy): 10 x Mp row factors (MlpBwdArgs::rs_ptr)
 };
 
 struct TrainState {
@@ -51,6 +52,7 @@ struct TrainState {
     int32_t *sidx = nullptr, *cidx = nullptr;   // device gather tables of the fused kernel's stream / constants
     bool fused_backward = false;    // data gradients by the fused chain kernel (needs the fused forward's mask records)
     bool frag = false;              // fused forward + backward: activation / gradient buffers are fragment-major (frag_index)
+    bool pair16 = false;            // ... and, under the float32 policy, the gradient buffers hold fp16 (hi, lo) pairs in their fp32 slots (nerf_kernels.h::kPair16)
     int32_t* bidx[2] = {nullptr, nullptr};      // gather tables of the backward stream: [0] plain, [1] with encoding tiles
     long long step = 0;
     size_t nblob = 0;
@@ -218,6 +220,7 @@ int ensure_pass(nerf_ctx* c, TPass& p, const PassDims& d) {
         if (xyz) r |= ensure(c, p.D[9], d.Mp * ldh9 * ea);
         r |= ensure(c, p.dxa, d.Mp * kBwdXyzLd * f);
         r |= ensure(c, p.dxb, d.Mp * kBwdXyzLd * f);
+        if (c->train->pair16) r |= ensure(c, p.rs, (size_t)10 * d.Mp * sizeof(uint16_t));
     }
     return r;
 }
@@ -336,6 +339,7 @@ int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
         off += (size_t)splits * (g.Kp + 1) * g.Nw;
     }
     if (t->mixed) launch_gemm_atb_f16_batch(q.gemm, c->stream, true);
+    else if (q.gemm.e[0].g_rs) launch_gemm_atb_p_batch(q.gemm, c->stream, true);     // (one format per trainer: all entries agree)
     else launch_gemm_atb_h_batch(q.gemm, c->stream, true);
     launch_reduce_grad_batch(q.red, c->stream);
     q.gemm.n = q.red.n = 0;
@@ -343,7 +347,8 @@ int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
 }
 
 void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
-           int n_src_off, long long Mp, const unsigned* gmax = nullptr, WgradQueue* q = nullptr) {
+           int n_src_off, long long Mp, const unsigned* gmax = nullptr, WgradQueue* q = nullptr,
+           const uint16_t* g_rs = nullptr /* pair16: G's row factors */) {
     const TLayer& L = n.L[l];
     GemmAtb g{};
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
@@ -353,6 +358,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     const bool wide = f16 && t->wgrad_wide && Ncols >= 256;
     g.a_f16 = t->mixed ? 1 : 0;
     g.frag = t->frag ? 1 : 0;
+    g.g_rs = f16 && !t->mixed ? g_rs : nullptr;
     const int want_splits = Ncols == 4 ? 1024 : wide ? kTrainSplitsWide : kTrainSplits;
     long long rps = (Mp + want_splits - 1) / want_splits;
     rps = t->frag ? (rps + 31) / 32 * 32 : (rps + 15) / 16 * 16;     // fragment-major operands: whole 32-row blocks
@@ -370,6 +376,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     }
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
     else if (t->mixed) launch_gemm_atb_f16(g, c->stream, wide);
+    else if (g.g_rs) launch_gemm_atb_p(g, c->stream, wide);
     else if (f16) launch_gemm_atb_h(g, c->stream, wide);
     else launch_gemm_atb(g, c->stream);
     r.partial = g.partial; r.splits = (int)((Mp + rps - 1) / rps);
@@ -435,38 +442,40 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         for (int l = 0; l < nrec; ++l) {
             b.mask_ptr[l] = (const uint32_t*)p.masks.p + (size_t)l * Mp * 8;
             b.d_ptr[l] = (float*)p.D[l].p;
+            b.rs_ptr[l] = t->pair16 ? (uint16_t*)p.rs.p + (size_t)l * Mp : nullptr;
         }
         b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
         launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream, xyz);
         WgradQueue wq;
+        auto RS = [&](int l) -> const uint16_t* { return t->pair16 ? b.rs_ptr[l] : nullptr; };   // row factors of d_ptr[l]
         if (xyz) {
             // get_network_only_xyz (src/NeRF.py:248-288): 10 = the rgb head on h9, 11 = the sigma head on h8 (the first 256
             // columns of C8), 9 = 256 -> 128 on the extra layer's output, 8 = that extra 256 -> 256 layer on h8
             float* H8b = (float*)p.H8b.p;
             wgrad(c, t, n, 10, H9, ldh9, Graw, 4, 4, 0, Mp);
             wgrad(c, t, n, 11, C8, kLdC8, Graw, 4, 4, 3, Mp);
-            wgrad(c, t, n, 9, H8b, ldh, b.d_ptr[9], ldh9, 128, 0, Mp, GM(0));
+            wgrad(c, t, n, 9, H8b, ldh, b.d_ptr[9], ldh9, 128, 0, Mp, GM(0), nullptr, RS(9));
             wq.open = t->wgrad_wide;
-            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh, 256, 0, Mp, GM(1), &wq);
+            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh, 256, 0, Mp, GM(1), &wq, RS(8));
         } else {
             wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
             wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0));
+            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0), nullptr, RS(8));
             wq.open = t->wgrad_wide;
         }
         const int g0 = xyz ? 1 : 0;                      // gmax group of D_l is g0 + 8 - l
-        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(g0 + 1), &wq);
-        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(g0 + 2), &wq);
-        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(g0 + 3), &wq);
-        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(g0 + 4), &wq);
-        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(g0 + 5), &wq);
-        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(g0 + 6), &wq);
-        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(g0 + 7), &wq);
+        wgrad(c, t, n, 7, H7, ldh, b.d_ptr[7], ldh, 256, 0, Mp, GM(g0 + 1), &wq, RS(7));
+        wgrad(c, t, n, 6, H6, ldh, b.d_ptr[6], ldh, 256, 0, Mp, GM(g0 + 2), &wq, RS(6));
+        wgrad(c, t, n, 5, H5, ldh, b.d_ptr[5], ldh, 256, 0, Mp, GM(g0 + 3), &wq, RS(5));
+        wgrad(c, t, n, 4, C4, kLdC4, b.d_ptr[4], ldh, 256, 0, Mp, GM(g0 + 4), &wq, RS(4));
+        wgrad(c, t, n, 3, H3, ldh, b.d_ptr[3], ldh, 256, 0, Mp, GM(g0 + 5), &wq, RS(3));
+        wgrad(c, t, n, 2, H2, ldh, b.d_ptr[2], ldh, 256, 0, Mp, GM(g0 + 6), &wq, RS(2));
+        wgrad(c, t, n, 1, H1, ldh, b.d_ptr[1], ldh, 256, 0, Mp, GM(g0 + 7), &wq, RS(1));
         // (the xyz encoding's columns 256.. of C4: in the fragment-major buffer a column offset c is 32 c ELEMENTS --
         // half the byte offset under the fp16 policy)
         const size_t xyz_off = (size_t)32 * 256;
         const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
-        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(g0 + 8), &wq);
+        wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(g0 + 8), &wq, RS(0));
         if (int r = wgrad_flush(c, t, wq, Mp)) return r;
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
@@ -814,7 +823,7 @@ void train_free(nerf_ctx* c) {
         DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
                         &p.rgb, &p.z};
         for (DevBuf* b : bs) free_buf(*b);
-        free_buf(p.masks); free_buf(p.dxa); free_buf(p.dxb);
+        free_buf(p.masks); free_buf(p.dxa); free_buf(p.dxb); free_buf(p.rs);
         for (DevBuf& b : p.D) free_buf(b);
     }
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
@@ -899,6 +908,7 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // GEMM forward as well)
     if (!t->fused_backward) t->fused_forward = false;
     t->frag = t->fused_forward && t->fused_backward;
+    t->pair16 = kPair16 && t->frag && !t->mixed;
     if (t->mixed && !(t->fused_forward && t->fused_backward)) {
         train_free(c);
         return fail("mixed_float16 training runs on the fused forward / backward kernels: unset NERF_TRAIN_FORWARD / "

@@ -52,6 +52,11 @@ struct GemmAtb {
     const unsigned* gmax;               // split-fp16 variant: bits of max|G| (written by G's producer); G is scaled to fp16 range
     int a_f16;                          // head_wgrad: A holds fp16 elements (lda in halfs); gemm_atb_f16: both operands do
     int frag;                           // A and G (not the heads' 4-wide G) are fragment-major (frag_layout.h::frag_index); rows_per_split % 32 == 0
+    // pair16 gradient operand of the fused float32-policy trainer (gemm_atb_p, train_kernels.hip; nerf_kernels.h::kPair16):
+    // G's fp32 slots hold the backward chain's packed operand as fp16 (hi, lo) pairs -- the 16 bytes of four consecutive
+    // features of a row are {hi01, hi23, lo01, lo23} -- carrying one power-of-two scale per row:
+    // true G = (hi + lo) * g_rs[row] (g_rs: upper half of the factor's fp32 bits).  A stays fp32.
+    const uint16_t* g_rs;               // non-null: G is pair16 (gemm_atb_p)
 };
 constexpr int kWgradBatchMax = 10;   // GEMMs per batched weight-gradient launch (the eight 256-wide layers of a pass fit)
 struct GemmAtbBatch { int n; int wg_end[kWgradBatchMax]; GemmAtb e[kWgradBatchMax]; };
@@ -60,6 +65,8 @@ void launch_gemm_atb(const GemmAtb& g, hipStream_t s);
 // three MFMA passes, fp32 accumulation; G is pre-scaled by a power of two so that its largest entry sits at 2^14
 void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide = false);   // wide: 256 x 256 tile, 512 threads
 void launch_gemm_atb_h_batch(GemmAtbBatch& b, hipStream_t s, bool wide);      // all entries in ONE launch (fills wg_end)
+void launch_gemm_atb_p(const GemmAtb& g, hipStream_t s, bool wide = false);   // pair16 operands (g.g_rs), same contract
+void launch_gemm_atb_p_batch(GemmAtbBatch& b, hipStream_t s, bool wide);
 void launch_head_wgrad(const GemmAtb& g, hipStream_t s);   // N = 4 (the heads): VALU kernel, same partial layout
 // mixed_float16 policy: A and G are fp16 rows (lda / ldg in halfs), one MFMA pass, no scaling (G carries the loss scale)
 void launch_gemm_atb_f16(const GemmAtb& g, hipStream_t s, bool wide = false);

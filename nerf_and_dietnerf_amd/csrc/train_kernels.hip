@@ -607,6 +607,242 @@ void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_atb_p: gemm_atb_h for a gradient operand that ARRIVES split ("pair16" buffers, float32 policy of the fused
+// trainer, nerf_kernels.h::kPair16).  The backward chain holds every pre-activation gradient as an fp16 (hi, lo) pair --
+// it is the next layer's MFMA operand -- and stores that pair in the value's fp32 slot: the 16 bytes of four consecutive
+// features of a row are {hi01, hi23, lo01, lo23} (packed halfs); same buffers, same addresses, same loads.
+//   A (activations): fp32 rows, split hi + lo while they are staged exactly as in gemm_atb_h (a pair16 stash was built
+// too and measured out: the forward had to assemble its store tuple with moves and spilled, +5 % on that kernel).
+//   G: the chain's packed operand D' = D * 2^s_row, one power of two PER SAMPLE ROW (mlp_bwd_f16x3.hip: every row's
+// operand peaks between 2^5 and 2^12 whatever its gradient is), with 2^-s_row stored per row as the upper half of its
+// fp32 bits (g_rs, 2 B per row and buffer).  The contraction runs over rows, so the row factor is applied while staging:
+// f_row = 2^-s_row * gscale (gscale: the buffer's true max|D| -> [2^8, 2^9), from the producer's gmax slots as before),
+// packed to fp16 pairs and multiplied onto the transposed (row, row + 1) pairs with v_pk_mul_f16 -- exact unless the
+// product drops below 2^-14 (absolute error 2^-25 against a buffer maximum of 2^8: 2^-33 of max|D|); rows whose factor
+// underflows fp16 altogether (peak below 2^-20 of the largest row's) are dropped, which an fp32 sum over the rows does to
+// them as well.  The target 2^8 instead of gemm_atb_h's 2^14 leaves room for a row whose outputs collapsed against its
+// operand's peak (factor up to 2^15 / its peak); beyond that the factor is clamped (finite, wrong by the clamp -- needs
+// a row-wise gain below 2^-11 in one layer).  Rows past the slab's end take factor 0.  The bias gradient (column sums of
+// true G) is v_dot2c_f32_f16 of the scaled pairs with (1, 1).  G's staging is ~3.5 vector instructions per element
+// (byte permutes, v_pk_mul, v_dot2c) where the fp32 rows took ~6 (scale, and, subtract, conversions, column sums).
+// Waves are specialised by operand (A: waves 0 .. W/64 - 1, G: the rest): two copies of the loop, chosen once per wave --
+// for W = 256 these are the SIMD partners of gemm_atb_h's stagger (the G half stages first, then computes).
+// What this kernel is bound by (profiles/r4_diagnostic_ab.txt): not its staging work -- with ONE MFMA pass instead of three
+// (timing-only build) the batched launch streams at 5.96 TB/s, with three at 4.95: per 16-row step ~2000 cycles of
+// barrier + LDS operand reads + staging do not overlap the 1536 MFMA cycles of the SIMD's two waves.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_p_kernel(const GemmAtbBatch bat) {
+    int lin = blockIdx.x;
+    const GemmAtb& g = bat.e[batch_entry(bat, lin)];
+    constexpr int kPl = W * kHColStride;          // bytes per plane
+    constexpr int WNW = W / 64;                   // waves along n (2 or 4); two along k
+    constexpr int KTL = W / 64;                   // 32-row k tiles per wave (2 or 4); two n tiles per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * kPl];    // planes: A hi, A lo, G hi, G lo
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave / WNW, wn = wave % WNW;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kt_n = (g.Kp + W - 1) / W, nt_n = (g.Nw + W - 1) / W, T = kt_n * nt_n;
+    const int n_splits = (int)((g.M + g.rows_per_split - 1) / g.rows_per_split);
+    if (lin >= T * n_splits) return;              // padding workgroups of a batch entry (its range is a multiple of 8)
+    const int grp = lin / (8 * T), rem = lin % (8 * T);
+    int split = grp * 8 + rem % 8, tile = rem / 8;
+    if (grp * 8 + 8 > n_splits) {
+        const int r2 = lin - grp * 8 * T, left = n_splits - grp * 8;
+        split = grp * 8 + r2 % left;
+        tile = r2 / left;
+    }
+    const int kb = (tile % kt_n) * W, nb = (tile / kt_n) * W;
+    const bool first_ktile = tile % kt_n == 0;
+    const long long ms = (long long)split * g.rows_per_split;
+    const long long me = ms + g.rows_per_split < g.M ? ms + g.rows_per_split : g.M;
+    // power-of-two scale of G: largest entry -> [2^8, 2^9)
+    unsigned mb = g.gmax ? g.gmax[lane] : 0u;                  // 64 slots per buffer (see the producers)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mb, o); mb = other > mb ? other : mb; }
+    int sexp = mb ? 127 + 8 - ((int)((mb >> 23) & 0xFF) - 127) : 127;
+    sexp = sexp < 1 ? 1 : sexp > 254 ? 254 : sexp;
+    const float gscale = __uint_as_float((unsigned)sexp << 23), ginv = 1.0f / gscale;
+    // staging role of this thread: operand (A: t < W, G: t >= W), rows 4 rg .. 4 rg + 3, columns 4 cg .. 4 cg + 3
+    const bool isG = __builtin_amdgcn_readfirstlane(wave) >= W / 64;
+    const int b = t & (W - 1), rg = b & 3, cg = b >> 2;
+    const int ld = isG ? g.ldg : g.lda;
+    const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
+    // threads whose columns lie outside the matrix read column block 0 (valid memory); what they stage only reaches
+    // outputs beyond Kp / Nw, which are not stored
+    const int col0 = on ? (isG ? nb : kb) + 4 * cg : 0;
+    // fragment-major operands (frag_layout.h::frag_index): the thread's 4 rows x 4 columns are 64 consecutive bytes
+    const uint4* src = reinterpret_cast<const uint4*>((isG ? g.G : g.A) + frag_index(ms + 4 * rg, col0, ld));
+    const uint16_t* rsp = g.g_rs + ms + 4 * rg;
+    const int wbase = (isG ? 2 : 0) * kPl + 4 * cg * kHColStride + rg * 8;
+
+    f32x16 acc[KTL][2];
+#pragma unroll
+    for (int a = 0; a < KTL; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;      // column sums of the scaled G block (bias gradient)
+
+#ifndef NERF_ATBP_STAGES
+#define NERF_ATBP_STAGES 3
+#endif
+    constexpr int NS = NERF_ATBP_STAGES;
+    uint4 R[NS][4];
+    uint2 S[NS];                                            // G role: the four rows' factors (upper halves of fp32 bits)
+    const long long steps = ms < me ? (me - ms) / 16 : 0;
+    auto fetch = [&](uint4 (&r)[4], uint2& s, long long st, auto role_g) {
+        const long long sc = st < steps ? st : steps - 1;
+        const uint4* q_ = src + ((size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64) / 4;
+        r[0] = q_[0]; r[1] = q_[1]; r[2] = q_[2]; r[3] = q_[3];
+        if constexpr (decltype(role_g)::value) s = *reinterpret_cast<const uint2*>(rsp + sc * 16);
+    };
+    // column j of the 4 x 4 block of a plane = halfs (row 0 .. row 3)[j]: two byte permutes (gemm_atb_f16_kernel::park1);
+    // a row's 16 bytes are {hi01, hi23, lo01, lo23}
+    auto park = [&](const uint4 (&r)[4], const uint2& s, long long st, int buf, auto role_g) {
+        unsigned char* w_ = &lds[buf][wbase];
+        constexpr uint32_t kLoSel = 0x05040100u, kHiSel = 0x07060302u;
+        if constexpr (!decltype(role_g)::value) {
+            // A: fp32 activations, split hi + lo here exactly as gemm_atb_h does (rows past the slab's end are re-read rows:
+            // finite, and they meet a zero factor on the G side)
+            auto cola = [&](int j, float c0, float c1, float c2, float c3) {
+                uint32_t h01, l01, h23, l23;
+                split_pack2(c0, c1, h01, l01);
+                split_pack2(c2, c3, h23, l23);
+                *reinterpret_cast<uint2*>(w_ + j * kHColStride) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(w_ + kPl + j * kHColStride) = make_uint2(l01, l23);
+            };
+            cola(0, __uint_as_float(r[0].x), __uint_as_float(r[1].x), __uint_as_float(r[2].x), __uint_as_float(r[3].x));
+            cola(1, __uint_as_float(r[0].y), __uint_as_float(r[1].y), __uint_as_float(r[2].y), __uint_as_float(r[3].y));
+            cola(2, __uint_as_float(r[0].z), __uint_as_float(r[1].z), __uint_as_float(r[2].z), __uint_as_float(r[3].z));
+            cola(3, __uint_as_float(r[0].w), __uint_as_float(r[1].w), __uint_as_float(r[2].w), __uint_as_float(r[3].w));
+        } else {
+            // f_row = 2^-s_row * gscale as fp16 pairs (rows 0,1 / rows 2,3); 0 for the steps past the slab's end
+            const bool live = st < steps;
+            const float kMaxF = 32768.0f;
+            const float f0 = fminf(__uint_as_float(s.x << 16) * gscale, kMaxF), f1 = fminf(__uint_as_float(s.x & 0xFFFF0000u) * gscale, kMaxF);
+            const float f2 = fminf(__uint_as_float(s.y << 16) * gscale, kMaxF), f3 = fminf(__uint_as_float(s.y & 0xFFFF0000u) * gscale, kMaxF);
+            const h2v f01 = {(_Float16)(live ? f0 : 0.f), (_Float16)(live ? f1 : 0.f)};
+            const h2v f23 = {(_Float16)(live ? f2 : 0.f), (_Float16)(live ? f3 : 0.f)};
+            const h2v one2 = {(_Float16)1.0f, (_Float16)1.0f};
+            auto colg = [&](int j, uint32_t a01, uint32_t a23, uint32_t l01, uint32_t l23, float& cs) {
+                const h2v h_a = __builtin_bit_cast(h2v, a01) * f01, h_b = __builtin_bit_cast(h2v, a23) * f23;
+                const h2v l_a = __builtin_bit_cast(h2v, l01) * f01, l_b = __builtin_bit_cast(h2v, l23) * f23;
+                cs = __builtin_amdgcn_fdot2(h_a, one2, cs, false);
+                cs = __builtin_amdgcn_fdot2(h_b, one2, cs, false);
+                cs = __builtin_amdgcn_fdot2(l_a, one2, cs, false);
+                cs = __builtin_amdgcn_fdot2(l_b, one2, cs, false);
+                *reinterpret_cast<uint2*>(w_ + j * kHColStride) = make_uint2(__builtin_bit_cast(uint32_t, h_a), __builtin_bit_cast(uint32_t, h_b));
+                *reinterpret_cast<uint2*>(w_ + kPl + j * kHColStride) = make_uint2(__builtin_bit_cast(uint32_t, l_a), __builtin_bit_cast(uint32_t, l_b));
+            };
+#define NERF_ATBP_G(J, X, Z, SEL, CS)                                                                                    \
+            colg(J, __builtin_amdgcn_perm(r[1].X, r[0].X, SEL), __builtin_amdgcn_perm(r[3].X, r[2].X, SEL),                \
+                 __builtin_amdgcn_perm(r[1].Z, r[0].Z, SEL), __builtin_amdgcn_perm(r[3].Z, r[2].Z, SEL), CS);
+            NERF_ATBP_G(0, x, z, kLoSel, cs0) NERF_ATBP_G(1, x, z, kHiSel, cs1) NERF_ATBP_G(2, y, w, kLoSel, cs2) NERF_ATBP_G(3, y, w, kHiSel, cs3)
+#undef NERF_ATBP_G
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const unsigned char* base = lds[buf];
+        h8v ah[KTL], al[KTL], gh[2], gl[2];
+#pragma unroll
+        for (int q = 0; q < KTL; ++q) {
+            const int ca = (wk * (W / 2) + q * 32 + li) * kHColStride + 16 * lh;
+            ah[q] = *reinterpret_cast<const h8v*>(base + ca);
+            al[q] = *reinterpret_cast<const h8v*>(base + kPl + ca);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cgd = (wn * 64 + q * 32 + li) * kHColStride + 16 * lh;
+            gh[q] = *reinterpret_cast<const h8v*>(base + 2 * kPl + cgd);
+            gl[q] = *reinterpret_cast<const h8v*>(base + 3 * kPl + cgd);
+        }
+#pragma unroll
+        for (int a = 0; a < KTL; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#ifndef NERF_DIAG_ATBP_1PASS     // timing-only diagnostic (wrong results): one MFMA pass instead of three
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gl[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], gh[c], acc[a][c], 0, 0, 0);
+#endif
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], gh[c], acc[a][c], 0, 0, 0);
+            }
+    };
+
+    if (steps > 0) {
+        // Two copies of the whole pipeline, chosen once per wave (the choice inside the loop body cost hundreds of spilled
+        // registers in gemm_atb_h).  The G waves of the 256-wide tile stage FIRST and compute after (gemm_atb_h's stagger of
+        // the SIMD partners w / w + 4: park writes buffer buf ^ 1, compute reads buf, both orders are legal between barriers).
+        auto run = [&](auto role_g) {
+            constexpr bool late = decltype(role_g)::value && NERF_ATB_STAGGER && W == 256;
+#pragma unroll
+            for (int q = 0; q < NS - 1; ++q) fetch(R[q], S[q], q, role_g);
+            park(R[0], S[0], 0, 0, role_g);
+            __syncthreads();
+            int buf = 0;
+            for (long long base_st = 1; base_st < steps; base_st += NS) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const long long st = base_st + i;
+                    fetch(R[(1 + i + NS - 2) % NS], S[(1 + i + NS - 2) % NS], st + NS - 2, role_g);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (late) {
+                        park(R[(1 + i) % NS], S[(1 + i) % NS], st, buf ^ 1, role_g);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute(buf);
+                    } else {
+                        compute(buf);
+                        __builtin_amdgcn_sched_barrier(0);
+                        park(R[(1 + i) % NS], S[(1 + i) % NS], st, buf ^ 1, role_g);
+                    }
+                    __syncthreads();
+                    buf ^= 1;
+                }
+            }
+            compute(buf);
+        };
+        if (isG) run(std::true_type{});
+        else run(std::false_type{});
+    }
+
+    float* part = g.partial + (size_t)split * (g.Kp + 1) * g.Nw;
+#pragma unroll
+    for (int a = 0; a < KTL; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = nb + wn * 64 + c * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + wk * (W / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < g.Kp && n < g.Nw) part[(size_t)k * g.Nw + n] = acc[a][c][r] * ginv;
+            }
+        }
+    // bias gradient: column sums of the G rows of this slab (in G's staged scale); the four row groups of a column block
+    // are four neighbouring lanes
+    cs0 += __shfl_xor(cs0, 1); cs1 += __shfl_xor(cs1, 1); cs2 += __shfl_xor(cs2, 1); cs3 += __shfl_xor(cs3, 1);
+    cs0 += __shfl_xor(cs0, 2); cs1 += __shfl_xor(cs1, 2); cs2 += __shfl_xor(cs2, 2); cs3 += __shfl_xor(cs3, 2);
+    if (first_ktile && isG && rg == 0 && nb + 4 * cg < g.Nw) {
+        float* prow = part + (size_t)g.Kp * g.Nw + nb + 4 * cg;
+        prow[0] = cs0 * ginv; prow[1] = cs1 * ginv; prow[2] = cs2 * ginv; prow[3] = cs3 * ginv;
+    }
+}
+
+void launch_gemm_atb_p_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
+    if (b.n <= 0) return;
+    const int wgs = batch_ranges(b, wide ? 256 : 128);
+    if (wide) hipLaunchKernelGGL(gemm_atb_p_kernel<256>, dim3((unsigned)wgs), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL(gemm_atb_p_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, s, b);
+}
+
+void launch_gemm_atb_p(const GemmAtb& g, hipStream_t s, bool wide) {
+    GemmAtbBatch b{};
+    b.n = 1; b.e[0] = g;
+    launch_gemm_atb_p_batch(b, s, wide);
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_atb_f16: the weight-gradient GEMM of the mixed_float16 policy.  A (activations) and G (loss-scaled pre-activation
 // gradients) arrive as fp16 rows from the single-pass stash forward / backward chain: half the bytes of the fp32 buffers
 // (this GEMM is bound by reading them), no hi/lo split and no conversion while staging -- a 4 x 4 block of halfs is
@@ -1393,12 +1629,12 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
     // element i of this row's xyz / direction encoding (columns 256 + i of the concat buffers)
     struct Cols {
         T* base; long long m; int ld; int frag;
-        __device__ T& operator[](int i) const { return base[frag ? frag_index(m, 256 + i, ld) : m * ld + 256 + i]; }
+        __device__ void set(int i, float v) const { base[frag ? frag_index(m, 256 + i, ld) : m * ld + 256 + i] = (T)v; }
     };
     const Cols ex{C4, m, kLdC4, frag}, ed{C8, m, kLdC8, frag};
     if (m >= M) {
-        for (int i = 0; i < kXyzPad; ++i) ex[i] = (T)0.f;
-        for (int i = 0; i < kDirPad; ++i) ed[i] = (T)0.f;
+        for (int i = 0; i < kXyzPad; ++i) ex.set(i, 0.f);
+        for (int i = 0; i < kDirPad; ++i) ed.set(i, 0.f);
         return;
     }
     const long long gm = row0 + m;
@@ -1417,24 +1653,24 @@ __global__ void train_encode_kernel(const float* __restrict__ o, const float* __
         v3[0] = dd.x; v3[1] = dd.y; v3[2] = dd.z;
     }
     for (int c = 0; c < 3; ++c) {
-        ex[c * 11] = (T)p[c];
+        ex.set(c * 11, p[c]);
         for (int k = 0; k < 5; ++k) {
             const float th = __fmul_rn(p[c], kPi * (float)(1 << k));
-            ex[c * 11 + 1 + 2 * k] = (T)sin_shifted(th, 0);
-            ex[c * 11 + 2 + 2 * k] = (T)sin_shifted(th, 1);
+            ex.set(c * 11 + 1 + 2 * k, sin_shifted(th, 0));
+            ex.set(c * 11 + 2 + 2 * k, sin_shifted(th, 1));
         }
     }
-    for (int i = 33; i < kXyzPad; ++i) ex[i] = (T)0.f;
+    for (int i = 33; i < kXyzPad; ++i) ex.set(i, 0.f);
     const int ncomp = n_angles > 0 ? n_angles + 1 : 0;     // the xyz-only network has no direction input
     for (int c = 0; c < ncomp; ++c) {
         const float v = n_angles == 2 ? v3[c] : (c == 0 ? v3[0] : v3[2]);
         for (int k = 0; k < 4; ++k) {
             const float th = __fmul_rn(v, kPi * (float)(1 << k));
-            ed[c * 8 + 2 * k] = (T)sin_shifted(th, 0);
-            ed[c * 8 + 2 * k + 1] = (T)sin_shifted(th, 1);
+            ed.set(c * 8 + 2 * k, sin_shifted(th, 0));
+            ed.set(c * 8 + 2 * k + 1, sin_shifted(th, 1));
         }
     }
-    for (int i = ncomp * 8; i < kDirPad; ++i) ed[i] = (T)0.f;
+    for (int i = ncomp * 8; i < kDirPad; ++i) ed.set(i, 0.f);
 }
 
 void launch_train_encode(const float* o, const float* d, const float* z, long long row0, long long M, int S,
