@@ -469,6 +469,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs& a) {
         const long long off128 = (m - j) * a.ld9 + (h * 32 + j) * 4; // this lane's slot in the fragment-major G9 rows
         // everything this tile reads from HBM, in one batch (a compiler-placed vmcnt wait drains the DMA ring once)
         const f32x4 graw = *reinterpret_cast<const f32x4*>(a.graw + m * 4);
+        if (a.dsig && h == 0) a.dsig[m] = graw[3];
         frag4 mq[NMQ];
 #pragma unroll
         for (int l = 0; l < NMQ; ++l)       // (read once: non-temporal, like the stash stores)

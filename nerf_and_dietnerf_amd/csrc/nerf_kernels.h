@@ -129,6 +129,8 @@ struct MlpBwdArgs {
     float* dx_ptr[2];        // dx variant: (Mp, 64) gradient w.r.t. the xyz encoding through layer 4 / through layer 0
     uint16_t* rs_ptr[10];    // kPair16 (3-pass kernels): per buffer d_ptr[l] and row the power of two r with true D = stored D' * r,
                              // as the upper half of r's fp32 bits
+    float* dsig;             // optional (Mp): column 3 of graw as a contiguous vector -- the sigma head's weight gradient rides in the
+                             // weight-gradient GEMM of layer 8, which stages C8 anyway (GemmAtb::sig_g)
     unsigned* gmax;          // 9 x 64 slots: bits of max|.| of G9 (slot group 0) and of D_(8-k) (slot group k); xyz-only
                              // network: 10 groups, group 0 = d_ptr[9], group k = d_ptr[9 - k]
     long long Mp;            // rows, multiple of 128

@@ -59,6 +59,7 @@ struct TrainState {
     TNet net[2];
     TPass pass[2];
     DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal, gmax;
+    DevBuf dsig;                    // (Mp) column 3 of Graw as a vector, written by the fused backward chain (GemmAtb::sig_g)
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
@@ -348,7 +349,8 @@ int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
 
 void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
            int n_src_off, long long Mp, const unsigned* gmax = nullptr, WgradQueue* q = nullptr,
-           const uint16_t* g_rs = nullptr /* pair16: G's row factors */) {
+           const uint16_t* g_rs = nullptr /* pair16: G's row factors */,
+           int sig_layer = -1 /* this GEMM also produces the weight gradient of head `sig_layer` (input = A) from t->dsig */) {
     const TLayer& L = n.L[l];
     GemmAtb g{};
     g.A = A; g.lda = lda; g.K = L.Kp; g.G = G; g.ldg = ldg; g.N = Ncols;
@@ -374,13 +376,29 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
         q->red.e[q->red.n++] = r;
         return;
     }
+    const int n_splits = (int)((Mp + rps - 1) / rps);
+    // the sigma head rides in this GEMM (gemm_atb_p / gemm_atb_f16, 128-wide tile): its slab sums land behind this GEMM's
+    const bool sig = sig_layer >= 0 && t->frag && !wide && Ncols == 128 && (t->mixed || g.g_rs) && t->dsig.p;
+    if (sig) {
+        g.sig_g = (const float*)t->dsig.p;
+        g.sig_partial = g.partial + (size_t)n_splits * (g.Kp + 1) * g.Nw;
+    }
     if (Ncols == 4) launch_head_wgrad(g, c->stream);
     else if (t->mixed) launch_gemm_atb_f16(g, c->stream, wide);
     else if (g.g_rs) launch_gemm_atb_p(g, c->stream, wide);
     else if (f16) launch_gemm_atb_h(g, c->stream, wide);
     else launch_gemm_atb(g, c->stream);
-    r.partial = g.partial; r.splits = (int)((Mp + rps - 1) / rps);
+    r.partial = g.partial; r.splits = n_splits;
     launch_reduce_grad(r, c->stream);
+    if (sig) {
+        const TLayer& Ls = n.L[sig_layer];
+        ReduceArgs rs{};
+        rs.partial = g.sig_partial; rs.Kp = g.Kp; rs.Nw = 1; rs.splits = n_splits;
+        rs.grad_w = n.grad + Ls.w_off; rs.grad_b = n.grad + Ls.b_off;
+        rs.K_real = Ls.K_real; rs.N_real = 1; rs.n_src_off = 0; rs.rowmap = Ls.rowmap;
+        rs.accumulate = t->acc_grads ? 1 : 0;
+        launch_reduce_grad(rs, c->stream);
+    }
 }
 
 void dgrad(nerf_ctx* c, const float* G, int ldg, int Kg, const float* Wrows, int ldb, int Nout, const float* H, int ldh,
@@ -445,6 +463,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
             b.rs_ptr[l] = t->pair16 ? (uint16_t*)p.rs.p + (size_t)l * Mp : nullptr;
         }
         b.dx_ptr[0] = (float*)p.dxa.p; b.dx_ptr[1] = (float*)p.dxb.p;
+        b.dsig = xyz ? nullptr : (float*)t->dsig.p;
         launch_mlp_bwd_f16x3(b, n.bdx, t->mixed, c->num_cus, c->stream, xyz);
         WgradQueue wq;
         auto RS = [&](int l) -> const uint16_t* { return t->pair16 ? b.rs_ptr[l] : nullptr; };   // row factors of d_ptr[l]
@@ -459,8 +478,9 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
             wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh, 256, 0, Mp, GM(1), &wq, RS(8));
         } else {
             wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
-            wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);
-            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0), nullptr, RS(8));
+            // the sigma head (layer 10: input C8 = [h8 | dir_enc], gradient column 3 of Graw) rides in layer 8's GEMM, which
+            // stages C8 anyway -- no second pass over that buffer
+            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0), nullptr, RS(8), 10);
             wq.open = t->wgrad_wide;
         }
         const int g0 = xyz ? 1 : 0;                      // gmax group of D_l is g0 + 8 - l
@@ -565,6 +585,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     r |= ensure(c, t->Gb, Mmax * 256 * f);
     r |= ensure(c, t->G9, Mmax * 128 * f);
     r |= ensure(c, t->Graw, Mmax * 4 * f);
+    r |= ensure(c, t->dsig, Mmax * f);
     r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
     r |= ensure(c, t->partial, (size_t)2 * kTrainSplitsWide * (kLdC4 + 1) * 256 * f);   // also holds a pass's batched slabs
     r |= ensure(c, t->d_rgb, N * 3 * f);
@@ -673,6 +694,7 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     r |= ensure(c, t->Gb, Mmax * 256 * f);
     r |= ensure(c, t->G9, Mmax * 128 * f);
     r |= ensure(c, t->Graw, Mmax * 4 * f);
+    r |= ensure(c, t->dsig, Mmax * f);
     r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
     r |= ensure(c, t->partial, (size_t)2 * kTrainSplitsWide * (kLdC4 + 1) * 256 * f);   // also holds a pass's batched slabs
     r |= ensure(c, t->d_wext, dc.M * f);
@@ -826,7 +848,7 @@ void train_free(nerf_ctx* c) {
         free_buf(p.masks); free_buf(p.dxa); free_buf(p.dxb); free_buf(p.rs);
         for (DevBuf& b : p.D) free_buf(b);
     }
-    DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
+    DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dsig, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
                     &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->opt,
                     &t->gsave[0], &t->gsave[1], &t->macc};
     for (DevBuf* b : bs) free_buf(*b);

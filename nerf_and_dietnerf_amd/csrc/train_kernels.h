@@ -57,6 +57,12 @@ struct GemmAtb {
     // features of a row are {hi01, hi23, lo01, lo23} -- carrying one power-of-two scale per row:
     // true G = (hi + lo) * g_rs[row] (g_rs: upper half of the factor's fp32 bits).  A stays fp32.
     const uint16_t* g_rs;               // non-null: G is pair16 (gemm_atb_p)
+    // The sigma head's weight gradient as a by-product of layer 8's GEMM (A = C8 is exactly the head's input, [h8 | dir_enc]):
+    // the threads that stage A also accumulate sum_rows A[row][k] * sig_g[row] on the VALU (fp32), one extra 16-byte load
+    // per thread and step instead of a second pass over C8 (0.9 GB per step under the float32 policy).  128-wide tile, one
+    // n tile only.  sig_partial: [splits][Kp + 1] (row Kp = sum of sig_g, the head's bias gradient)
+    const float* sig_g;                 // (M) d_sigma per sample row (MlpBwdArgs::dsig)
+    float* sig_partial;
 };
 constexpr int kWgradBatchMax = 10;   // GEMMs per batched weight-gradient launch (the eight 256-wide layers of a pass fit)
 struct GemmAtbBatch { int n; int wg_end[kWgradBatchMax]; GemmAtb e[kWgradBatchMax]; };

@@ -631,7 +631,8 @@ void launch_gemm_atb_h(const GemmAtb& g, hipStream_t s, bool wide) {
 // (timing-only build) the batched launch streams at 5.96 TB/s, with three at 4.95: per 16-row step ~2000 cycles of
 // barrier + LDS operand reads + staging do not overlap the 1536 MFMA cycles of the SIMD's two waves.
 // ------------------------------------------------------------------------------------------------
-template <int W>
+// SIG: the entry carries the sigma head's weight gradient as a by-product (GemmAtb::sig_g; W = 128, one n tile)
+template <int W, bool SIG = false>
 __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_p_kernel(const GemmAtbBatch bat) {
     int lin = blockIdx.x;
     const GemmAtb& g = bat.e[batch_entry(bat, lin)];
@@ -684,6 +685,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;      // column sums of the scaled G block (bias gradient)
+    float sg0 = 0.f, sg1 = 0.f, sg2 = 0.f, sg3 = 0.f, sgb = 0.f;   // SIG, A role: sum_rows A[row][col j] * d_sigma[row]; sum of d_sigma
+    const float* sigp = SIG ? g.sig_g + ms + 4 * rg : nullptr;
 
 #ifndef NERF_ATBP_STAGES
 #define NERF_ATBP_STAGES 3
@@ -691,16 +694,18 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     constexpr int NS = NERF_ATBP_STAGES;
     uint4 R[NS][4];
     uint2 S[NS];                                            // G role: the four rows' factors (upper halves of fp32 bits)
+    float4 SGv[SIG ? NS : 1];                               // SIG, A role: d_sigma of the four rows
     const long long steps = ms < me ? (me - ms) / 16 : 0;
-    auto fetch = [&](uint4 (&r)[4], uint2& s, long long st, auto role_g) {
+    auto fetch = [&](uint4 (&r)[4], uint2& s, float4& sgv, long long st, auto role_g) {
         const long long sc = st < steps ? st : steps - 1;
         const uint4* q_ = src + ((size_t)(sc >> 1) * 32 * ld + (sc & 1) * 64) / 4;
         r[0] = q_[0]; r[1] = q_[1]; r[2] = q_[2]; r[3] = q_[3];
         if constexpr (decltype(role_g)::value) s = *reinterpret_cast<const uint2*>(rsp + sc * 16);
+        else if constexpr (SIG) sgv = *reinterpret_cast<const float4*>(sigp + sc * 16);
     };
     // column j of the 4 x 4 block of a plane = halfs (row 0 .. row 3)[j]: two byte permutes (gemm_atb_f16_kernel::park1);
     // a row's 16 bytes are {hi01, hi23, lo01, lo23}
-    auto park = [&](const uint4 (&r)[4], const uint2& s, long long st, int buf, auto role_g) {
+    auto park = [&](const uint4 (&r)[4], const uint2& s, const float4& sgv, long long st, int buf, auto role_g) {
         unsigned char* w_ = &lds[buf][wbase];
         constexpr uint32_t kLoSel = 0x05040100u, kHiSel = 0x07060302u;
         if constexpr (!decltype(role_g)::value) {
@@ -717,6 +722,15 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             cola(1, __uint_as_float(r[0].y), __uint_as_float(r[1].y), __uint_as_float(r[2].y), __uint_as_float(r[3].y));
             cola(2, __uint_as_float(r[0].z), __uint_as_float(r[1].z), __uint_as_float(r[2].z), __uint_as_float(r[3].z));
             cola(3, __uint_as_float(r[0].w), __uint_as_float(r[1].w), __uint_as_float(r[2].w), __uint_as_float(r[3].w));
+            if constexpr (SIG) {        // (rows past the slab's end are re-read rows: their d_sigma counts as zero)
+                const bool live = st < steps;
+                const float d0 = live ? sgv.x : 0.f, d1 = live ? sgv.y : 0.f, d2 = live ? sgv.z : 0.f, d3 = live ? sgv.w : 0.f;
+                sg0 = fmaf(__uint_as_float(r[3].x), d3, fmaf(__uint_as_float(r[2].x), d2, fmaf(__uint_as_float(r[1].x), d1, fmaf(__uint_as_float(r[0].x), d0, sg0))));
+                sg1 = fmaf(__uint_as_float(r[3].y), d3, fmaf(__uint_as_float(r[2].y), d2, fmaf(__uint_as_float(r[1].y), d1, fmaf(__uint_as_float(r[0].y), d0, sg1))));
+                sg2 = fmaf(__uint_as_float(r[3].z), d3, fmaf(__uint_as_float(r[2].z), d2, fmaf(__uint_as_float(r[1].z), d1, fmaf(__uint_as_float(r[0].z), d0, sg2))));
+                sg3 = fmaf(__uint_as_float(r[3].w), d3, fmaf(__uint_as_float(r[2].w), d2, fmaf(__uint_as_float(r[1].w), d1, fmaf(__uint_as_float(r[0].w), d0, sg3))));
+                sgb += (d0 + d1) + (d2 + d3);
+            }
         } else {
             // f_row = 2^-s_row * gscale as fp16 pairs (rows 0,1 / rows 2,3); 0 for the steps past the slab's end
             const bool live = st < steps;
@@ -778,24 +792,24 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         auto run = [&](auto role_g) {
             constexpr bool late = decltype(role_g)::value && NERF_ATB_STAGGER && W == 256;
 #pragma unroll
-            for (int q = 0; q < NS - 1; ++q) fetch(R[q], S[q], q, role_g);
-            park(R[0], S[0], 0, 0, role_g);
+            for (int q = 0; q < NS - 1; ++q) fetch(R[q], S[q], SGv[SIG ? q : 0], q, role_g);
+            park(R[0], S[0], SGv[0], 0, 0, role_g);
             __syncthreads();
             int buf = 0;
             for (long long base_st = 1; base_st < steps; base_st += NS) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const long long st = base_st + i;
-                    fetch(R[(1 + i + NS - 2) % NS], S[(1 + i + NS - 2) % NS], st + NS - 2, role_g);
+                    fetch(R[(1 + i + NS - 2) % NS], S[(1 + i + NS - 2) % NS], SGv[SIG ? (1 + i + NS - 2) % NS : 0], st + NS - 2, role_g);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (late) {
-                        park(R[(1 + i) % NS], S[(1 + i) % NS], st, buf ^ 1, role_g);
+                        park(R[(1 + i) % NS], S[(1 + i) % NS], SGv[SIG ? (1 + i) % NS : 0], st, buf ^ 1, role_g);
                         __builtin_amdgcn_sched_barrier(0);
                         compute(buf);
                     } else {
                         compute(buf);
                         __builtin_amdgcn_sched_barrier(0);
-                        park(R[(1 + i) % NS], S[(1 + i) % NS], st, buf ^ 1, role_g);
+                        park(R[(1 + i) % NS], S[(1 + i) % NS], SGv[SIG ? (1 + i) % NS : 0], st, buf ^ 1, role_g);
                     }
                     __syncthreads();
                     buf ^= 1;
@@ -827,12 +841,26 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         float* prow = part + (size_t)g.Kp * g.Nw + nb + 4 * cg;
         prow[0] = cs0 * ginv; prow[1] = cs1 * ginv; prow[2] = cs2 * ginv; prow[3] = cs3 * ginv;
     }
+    if constexpr (SIG) {     // the sigma head's gradient: the four row groups of a column block are four neighbouring lanes
+        sg0 += __shfl_xor(sg0, 1); sg1 += __shfl_xor(sg1, 1); sg2 += __shfl_xor(sg2, 1); sg3 += __shfl_xor(sg3, 1); sgb += __shfl_xor(sgb, 1);
+        sg0 += __shfl_xor(sg0, 2); sg1 += __shfl_xor(sg1, 2); sg2 += __shfl_xor(sg2, 2); sg3 += __shfl_xor(sg3, 2); sgb += __shfl_xor(sgb, 2);
+        if (!isG && rg == 0 && nb == 0) {
+            float* sp = g.sig_partial + (size_t)split * (g.Kp + 1);
+            const int k0 = kb + 4 * cg;
+            if (k0 + 0 < g.Kp) sp[k0 + 0] = sg0;
+            if (k0 + 1 < g.Kp) sp[k0 + 1] = sg1;
+            if (k0 + 2 < g.Kp) sp[k0 + 2] = sg2;
+            if (k0 + 3 < g.Kp) sp[k0 + 3] = sg3;
+            if (first_ktile && cg == 0) sp[g.Kp] = sgb;
+        }
+    }
 }
 
 void launch_gemm_atb_p_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
     if (b.n <= 0) return;
     const int wgs = batch_ranges(b, wide ? 256 : 128);
     if (wide) hipLaunchKernelGGL(gemm_atb_p_kernel<256>, dim3((unsigned)wgs), dim3(512), 0, s, b);
+    else if (b.n == 1 && b.e[0].sig_g && b.e[0].Nw <= 128) hipLaunchKernelGGL((gemm_atb_p_kernel<128, true>), dim3((unsigned)wgs), dim3(256), 0, s, b);
     else hipLaunchKernelGGL(gemm_atb_p_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, s, b);
 }
 
@@ -851,8 +879,10 @@ void launch_gemm_atb_p(const GemmAtb& g, hipStream_t s, bool wide) {
 // gradient that left the fp16 range arrives as Inf and makes the partial sums non-finite: the loss-scale logic skips
 // that step (src/NeRF.py:159-163 under LossScaleOptimizer).
 // ------------------------------------------------------------------------------------------------
-template <int W, bool FRAG>
-__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 ? 3 : 2))) void gemm_atb_f16_kernel(const GemmAtbBatch bat) {
+// SIG: the entry carries the sigma head's weight gradient as a by-product (GemmAtb::sig_g; W = 128, one n tile): fp16 A x fp32
+// d_sigma, accumulated in fp32 (v_fma_mix_f32: no conversion instructions)
+template <int W, bool FRAG, bool SIG = false>
+__global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 128 && !SIG ? 3 : 2))) void gemm_atb_f16_kernel(const GemmAtbBatch bat) {
     int lin = blockIdx.x;
     const GemmAtb& g = bat.e[batch_entry(bat, lin)];
     constexpr int kPl = W * kHColStride;
@@ -886,6 +916,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     const bool on = isG ? (nb + 4 * cg < g.N) : (kb + 4 * cg < g.K);
     // threads whose columns lie outside the matrix read column block 0 (valid memory) and park zeros
     const int col = on ? (isG ? nb : kb) + 4 * cg : 0;
+    float sg0 = 0.f, sg1 = 0.f, sg2 = 0.f, sg3 = 0.f, sgb = 0.f;   // SIG, A threads: sum_rows A[row][col j] * d_sigma[row]; sum of d_sigma
+    const float* sigp = SIG ? g.sig_g + ms + 4 * rg : nullptr;
     // fragment-major operands (frag_layout.h::frag_index): the thread's 4 rows x 4 columns are 16 consecutive elements
     // -- with FRAG known at compile time they are fetched as two 16-byte loads instead of four 8-byte ones
     const int rs = FRAG ? 4 : ld;                                     // elements between two of its rows
@@ -915,6 +947,7 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
 #endif
     constexpr int NS = W == 256 ? NERF_ATBF_STAGES_WIDE : NERF_ATBF_STAGES;   // the 256-wide tile has 128 accumulator registers
     uint2 R[NS][PB][4];
+    float4 SGv[SIG ? NS : 1][PB];      // SIG: d_sigma of the thread's four rows per sub-step (loaded by every thread: no load sits in a branch)
     auto h2f = [](uint32_t w, int hi) -> float {
         const h2v v = __builtin_bit_cast(h2v, w);
         return (float)v[hi];
@@ -934,9 +967,15 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
             r[3] = *reinterpret_cast<const uint2*>(q_ + 3 * (size_t)rs);
         }
     };
-    auto fetch = [&](uint2 (&r)[PB][4], long long pj) {
+    auto fetch = [&](uint2 (&r)[PB][4], float4 (&sgv)[PB], long long pj) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) fetch1(r[p], pj * PB + p);
+        for (int p = 0; p < PB; ++p) {
+            fetch1(r[p], pj * PB + p);
+            if constexpr (SIG) {
+                const long long st = pj * PB + p, sc = st < steps ? st : steps - 1;
+                sgv[p] = *reinterpret_cast<const float4*>(sigp + sc * 16);
+            }
+        }
     };
     // column j of the 4 x 4 block = halfs (r0, r1, r2, r3)[j]: two byte permutes per column
     auto park1 = [&](const uint2 (&r_)[4], bool live, unsigned char* lbuf) {
@@ -956,9 +995,26 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         *reinterpret_cast<uint2*>(w_ + 3 * kHColStride) = make_uint2(__builtin_amdgcn_perm(r[1].y, r[0].y, 0x07060302u), __builtin_amdgcn_perm(r[3].y, r[2].y, 0x07060302u));
     };
 
-    auto park = [&](const uint2 (&r)[PB][4], long long pj, int buf) {
+    auto half_of = [](uint32_t w, int hi) -> _Float16 { return __builtin_bit_cast(h2v, w)[hi]; };
+    auto park = [&](const uint2 (&r)[PB][4], const float4 (&sgv)[PB], long long pj, int buf) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) park1(r[p], on && pj * PB + p < steps, lds[buf][p]);
+        for (int p = 0; p < PB; ++p) {
+            park1(r[p], on && pj * PB + p < steps, lds[buf][p]);
+            if constexpr (SIG) {
+                if (!isG) {      // (wave-uniform: the A threads are whole waves)
+                    const bool live = pj * PB + p < steps;
+                    const float d[4] = {live ? sgv[p].x : 0.f, live ? sgv[p].y : 0.f, live ? sgv[p].z : 0.f, live ? sgv[p].w : 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sg0 = fmaf((float)half_of(r[p][e].x, 0), d[e], sg0);
+                        sg1 = fmaf((float)half_of(r[p][e].x, 1), d[e], sg1);
+                        sg2 = fmaf((float)half_of(r[p][e].y, 0), d[e], sg2);
+                        sg3 = fmaf((float)half_of(r[p][e].y, 1), d[e], sg3);
+                    }
+                    sgb += (d[0] + d[1]) + (d[2] + d[3]);
+                }
+            }
+        }
     };
 
     auto compute1 = [&](const unsigned char* base) {
@@ -985,8 +1041,8 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
     if (steps > 0) {
         const long long groups = (steps + PB - 1) / PB;
 #pragma unroll
-        for (int q = 0; q < NS - 1; ++q) fetch(R[q], q);
-        park(R[0], 0, 0);
+        for (int q = 0; q < NS - 1; ++q) fetch(R[q], SGv[SIG ? q : 0], q);
+        park(R[0], SGv[0], 0, 0);
         __syncthreads();
         int buf = 0;
         // group st: registers in slot st % NS; unrolled by NS for static register indices.  The last round may run past
@@ -996,16 +1052,16 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const long long st = base_st + i;
-                    fetch(R[(1 + i + NS - 2) % NS], st + NS - 2);
+                    fetch(R[(1 + i + NS - 2) % NS], SGv[SIG ? (1 + i + NS - 2) % NS : 0], st + NS - 2);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (decltype(late_c)::value) {
-                        park(R[(1 + i) % NS], st, buf ^ 1);
+                        park(R[(1 + i) % NS], SGv[SIG ? (1 + i) % NS : 0], st, buf ^ 1);
                         __builtin_amdgcn_sched_barrier(0);
                         compute(buf);
                     } else {
                         compute(buf);
                         __builtin_amdgcn_sched_barrier(0);
-                        park(R[(1 + i) % NS], st, buf ^ 1);
+                        park(R[(1 + i) % NS], SGv[SIG ? (1 + i) % NS : 0], st, buf ^ 1);
                     }
                     __syncthreads();
                     buf ^= 1;
@@ -1035,6 +1091,19 @@ __global__ __launch_bounds__(2 * W) __attribute__((amdgpu_waves_per_eu(2, W == 1
         float* prow = part + (size_t)g.Kp * g.Nw + nb + 4 * cg;
         prow[0] = cs0; prow[1] = cs1; prow[2] = cs2; prow[3] = cs3;
     }
+    if constexpr (SIG) {     // the sigma head's gradient: the four row groups of a column block are four neighbouring lanes
+        sg0 += __shfl_xor(sg0, 1); sg1 += __shfl_xor(sg1, 1); sg2 += __shfl_xor(sg2, 1); sg3 += __shfl_xor(sg3, 1); sgb += __shfl_xor(sgb, 1);
+        sg0 += __shfl_xor(sg0, 2); sg1 += __shfl_xor(sg1, 2); sg2 += __shfl_xor(sg2, 2); sg3 += __shfl_xor(sg3, 2); sgb += __shfl_xor(sgb, 2);
+        if (!isG && rg == 0 && nb == 0) {
+            float* sp = g.sig_partial + (size_t)split * (g.Kp + 1);
+            const int k0 = kb + 4 * cg;
+            if (k0 + 0 < g.Kp) sp[k0 + 0] = sg0;
+            if (k0 + 1 < g.Kp) sp[k0 + 1] = sg1;
+            if (k0 + 2 < g.Kp) sp[k0 + 2] = sg2;
+            if (k0 + 3 < g.Kp) sp[k0 + 3] = sg3;
+            if (first_ktile && cg == 0) sp[g.Kp] = sgb;
+        }
+    }
 }
 
 void launch_gemm_atb_f16_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
@@ -1045,7 +1114,8 @@ void launch_gemm_atb_f16_batch(GemmAtbBatch& b, hipStream_t s, bool wide) {
         if (frag) hipLaunchKernelGGL((gemm_atb_f16_kernel<256, true>), dim3((unsigned)wgs), dim3(512), 0, s, b);
         else hipLaunchKernelGGL((gemm_atb_f16_kernel<256, false>), dim3((unsigned)wgs), dim3(512), 0, s, b);
     } else {
-        if (frag) hipLaunchKernelGGL((gemm_atb_f16_kernel<128, true>), dim3((unsigned)wgs), dim3(256), 0, s, b);
+        if (frag && b.n == 1 && b.e[0].sig_g && b.e[0].Nw <= 128) hipLaunchKernelGGL((gemm_atb_f16_kernel<128, true, true>), dim3((unsigned)wgs), dim3(256), 0, s, b);
+        else if (frag) hipLaunchKernelGGL((gemm_atb_f16_kernel<128, true>), dim3((unsigned)wgs), dim3(256), 0, s, b);
         else hipLaunchKernelGGL((gemm_atb_f16_kernel<128, false>), dim3((unsigned)wgs), dim3(256), 0, s, b);
     }
 }
