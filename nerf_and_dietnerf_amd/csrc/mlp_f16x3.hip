@@ -32,6 +32,10 @@ __device__ unsigned long long g_stamps_h[16];
 //   back as the last tile's chain retires the k-steps that read them; tile 7 lands in xh/xl[14..15].
 // FAST = single-pass fp16 mode (NERF_PRECISION_F16: the reference's production mixed_float16 numerics): only the
 // hi*hi product is formed and the activations are rounded (RNE) to fp16 between layers; same stream, same schedule.
+// Since round 4 its hidden layers use the two-tile render kernel's packed-pair epilogue (NERF_FAST_PACKED_EPI): the fp32
+// sum (bias = C-in) is cast to fp16 FIRST, LeakyReLU runs on the pair in fp16 with alpha rounded to fp16 -- where Keras'
+// mixed_float16 LeakyReLU rounds; the oracles' emulations round there too (oracle.mlp_forward_fp16(..., "c_in"),
+// oracle.train_oracle._LRelu16).  The stash forward of the mixed_float16 trainer: 966 -> 908 us per step.
 // STASH = training forward: every activation is also written as fp32 to HBM (st_prev: the previous layer's output rows
 // of this lane's sample, for its PENDING tile 7; st_cur: this layer's), four consecutive features per float4 store, in the
 // FRAGMENT-MAJOR layout of frag_layout.h::frag_index (a store instruction writes 1 KiB / 512 B of consecutive bytes).
@@ -164,6 +168,35 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
         else { nh[n][e >> 1] = ph; if constexpr (!FAST) nl[n][e >> 1] = pl; }
     };
 
+    // FAST, packed-pair epilogue (NERF_FAST_PACKED_EPI, the two-tile render kernel's: mlp_f16_2t.hip): the accumulator pair is
+    // converted FIRST (v_cvt_pk_f16_f32), then alpha and max act on the pair (v_pk_mul_f16, v_pk_max_f16): 1.5 plain vector
+    // instructions per value instead of 2.5 (the bias is the accumulator's C-in here)
+#ifndef NERF_FAST_PACKED_EPI
+#define NERF_FAST_PACKED_EPI 1
+#endif
+    constexpr bool kPackedEpi = FAST && NERF_FAST_PACKED_EPI != 0;
+    const uint32_t alpha2 = pack_h2(alpha, alpha);
+    (void)alpha2;
+    auto act_pair = [&](float v0, float v1) -> uint32_t {
+        const uint32_t pk = pack_h2(v0, v1);
+        uint32_t q, y;
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(q) : "v"(pk), "v"(alpha2));
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(y) : "v"(pk), "v"(q));
+        return y;
+    };
+    auto store_pair_p = [&](auto utc, auto rc, uint32_t ph, auto dest_sel, auto pend_sel) {
+        constexpr int ut = decltype(utc)::value;
+        constexpr int r = decltype(rc)::value;
+        constexpr int n = 2 * ut + (r >> 3), e = r & 7;
+        if constexpr (STASH) {
+            stash4h(utc, rc, ph, decltype(pend_sel)::value ? st_prev : st_cur);
+            if constexpr (decltype(pend_sel)::value) mk_prev[ut >> 1] = mask_push(mk_prev[ut >> 1], ph);
+            else mk_cur[ut >> 1] = mask_push(mk_cur[ut >> 1], ph);
+        }
+        if constexpr (decltype(dest_sel)::value) xh[n][e >> 1] = ph;
+        else nh[n][e >> 1] = ph;
+    };
+    (void)act_pair; (void)store_pair_p;
     float ycarry = 0.f;
     (void)ycarry;
     static_for<0, NU>([&](auto uc) {
@@ -233,7 +266,13 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
-            if constexpr (kPend) {
+            if constexpr (kPend && kPackedEpi) {
+                constexpr int er = 2 * n;
+                store_pair_p(std::integral_constant<int, 7>{}, std::integral_constant<int, er>{}, act_pair(prv[er], prv[er + 1]), std::true_type{}, std::true_type{});
+            } else if constexpr (kPrevS && !kXc && kPackedEpi) {
+                if constexpr ((n & 1) == 1)
+                    store_pair_p(std::integral_constant<int, et>{}, std::integral_constant<int, n - 1>{}, act_pair(prv[n - 1], prv[n]), std::false_type{}, std::false_type{});
+            } else if constexpr (kPend) {
                 constexpr int er = 2 * n;
                 const float y0 = act(prv[er]), y1 = act(prv[er + 1]);
                 store_pair(std::integral_constant<int, 7>{}, std::integral_constant<int, er>{}, y0, y1, std::true_type{}, std::true_type{});
@@ -270,6 +309,12 @@ __device__ __forceinline__ void layer_body_h(Pipe& p, uint32_t lane16, uint32_t 
             if constexpr (BODY == BODY_PE && u > 0 && n == 0) {
                 static_for<0, 8>([&](auto pc) {
                     constexpr int r = 2 * decltype(pc)::value;
+                    if constexpr (kPackedEpi) {
+                        const uint32_t ph = act_pair(prv[r], prv[r + 1]);
+                        if constexpr (u - 1 <= 5) store_pair_p(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, ph, std::true_type{}, std::false_type{});
+                        else store_pair_p(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, ph, std::false_type{}, std::false_type{});
+                        return;
+                    }
                     const float z0 = act(prv[r]), z1 = act(prv[r + 1]);
                     if constexpr (u - 1 <= 5) store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::true_type{}, std::false_type{});
                     else store_pair(std::integral_constant<int, u - 1>{}, std::integral_constant<int, r>{}, z0, z1, std::false_type{}, std::false_type{});

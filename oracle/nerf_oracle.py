@@ -321,14 +321,24 @@ def mlp_forward_fp16(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: n
     256-wide contraction -- weights and layer inputs -- rounded to fp16 (RNE), products accumulated in fp32; the
     128 -> 3 rgb head in fp32 on the unrounded last hidden layer.
 
-    packed_epilogue = False (the trainer's stash forward and the one-tile render kernel, csrc/mlp_f16x3.hip FAST):
-    fp32 bias as the accumulator's start value, LeakyReLU in fp32, activations rounded to fp16 between layers.
+    packed_epilogue = False (rounds 2-3; kept as the "visibly further away" emulation of the parity tests): fp32 bias as the
+    accumulator's start value, LeakyReLU in fp32, activations rounded to fp16 between layers.
     packed_epilogue = True (the two-tile render kernel, csrc/mlp_f16_2t.hip, round 4): layers 0..7 round where Keras'
     mixed_float16 Dense rounds -- the fp32 sum is cast to fp16 FIRST (v_cvt_pk_f16_f32), then the fp16 bias is added
     (v_pk_add_f16: one rounding), then LeakyReLU in fp16 with alpha rounded to fp16 (v_pk_mul_f16, v_pk_max_f16);
-    layer 8 (which feeds the fp32 head) and the sigma head keep the fp32 epilogue."""
+    layer 8 (which feeds the fp32 head) and the sigma head keep the fp32 epilogue.
+    packed_epilogue = "c_in" (the trainer's stash forward and the one-tile render kernel, csrc/mlp_f16x3.hip FAST, since
+    round 4): the fp32 bias is the accumulator's start value, the fp32 sum (bias included) is cast to fp16, then
+    LeakyReLU in fp16 as above (v_pk_mul_f16, v_pk_max_f16)."""
     q = lambda a: np.asarray(a, F32).astype(np.float16).astype(F32)
-    if packed_epilogue:
+    if packed_epilogue == "c_in":
+        a16 = np.float16(alpha)
+
+        def dense(x, k, b):
+            y = (x @ q(k) + b).astype(np.float16)                                   # cast of the fp32 accumulator (bias inside)
+            z = (y.astype(F32) * F32(a16)).astype(np.float16)
+            return np.maximum(y, z).astype(F32)
+    elif packed_epilogue:
         a16 = np.float16(alpha)
 
         def dense(x, k, b):
@@ -350,6 +360,11 @@ def mlp_forward_fp16(layers: Sequence[Tuple[np.ndarray, np.ndarray]], xyz_enc: n
     rgb = h8 @ layers[9][0] + layers[9][1]
     sigma = hd @ q(layers[10][0]) + layers[10][1]
     return np.concatenate([rgb, sigma], axis=-1).astype(F32)
+
+
+def mlp_forward_fp16_train(layers, xyz_enc, dir_enc, alpha: float = 0.05) -> np.ndarray:
+    """mlp_forward_fp16 as the mixed_float16 trainer's stash forward computes it (mlp_f16x3.hip FAST + STASH)."""
+    return mlp_forward_fp16(layers, xyz_enc, dir_enc, alpha, packed_epilogue="c_in")
 
 
 def mlp_forward_fp16_render(layers, xyz_enc, dir_enc, alpha: float = 0.05) -> np.ndarray:

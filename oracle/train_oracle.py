@@ -143,19 +143,41 @@ class _RgbHead16(torch.autograd.Function):
         return g @ w.t(), _r16(y9).t() @ g, g.sum(0)
 
 
+class _LRelu16(torch.autograd.Function):
+    """LeakyReLU of the stash forward's packed-pair epilogue (mlp_f16x3.hip FAST, round 4): the fp32 sum is cast to fp16
+    FIRST, then y = max(x, fp16(alpha16 * x)) in fp16 (v_pk_mul_f16, v_pk_max_f16; alpha rounded to fp16) -- where Keras'
+    mixed_float16 LeakyReLU rounds.  Backward: the kernels' LeakyReLU' record is y's SIGN bit, the factor alpha or 1."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x16 = _r16(x)
+        a16 = float(np.float16(alpha))
+        y = torch.maximum(x16, _r16(x16 * a16))
+        neg = torch.signbit(y)
+        ctx.save_for_backward(neg)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (neg,) = ctx.saved_tensors
+        return torch.where(neg, g * ctx.alpha, g), None
+
+
 def _mlp16(p: Sequence[torch.Tensor], xyz_enc, dir_enc, alpha: float, loss_scale: float):
     """_mlp under the library's mixed_float16 arithmetic (view-direction network, or the xyz-only one: 24 tensors)."""
     lrelu = lambda t: torch.nn.functional.leaky_relu(t, alpha)
+    lrelu16 = lambda t: _LRelu16.apply(t, alpha)      # cast to fp16, then LeakyReLU in fp16: already fp16 values
     dense = lambda x, i, st=True, valu=False: _Dense16.apply(x, p[2 * i], p[2 * i + 1], loss_scale, st, valu)
     xq = _ste16(xyz_enc)
-    h = _ste16(lrelu(dense(xq, 0)))
+    h = lrelu16(dense(xq, 0))
     for i in (1, 2, 3):
-        h = _ste16(lrelu(dense(h, i)))
-    h = _ste16(lrelu(dense(torch.cat([xq, h], -1), 4)))
+        h = lrelu16(dense(h, i))
+    h = lrelu16(dense(torch.cat([xq, h], -1), 4))
     for i in (5, 6, 7):
-        h = _ste16(lrelu(dense(h, i)))
+        h = lrelu16(dense(h, i))
     if len(p) == 24:                                  # get_network_only_xyz, src/NeRF.py:265-287
-        h8b = _ste16(lrelu(dense(h, 8)))
+        h8b = lrelu16(dense(h, 8))
         y9 = lrelu(dense(h8b, 9))                     # stays fp32 for the VALU head
         return torch.cat([_RgbHead16.apply(y9, p[20], p[21]), dense(h, 11, False, True)], -1)
     dq = _ste16(dir_enc)

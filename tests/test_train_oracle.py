@@ -184,7 +184,7 @@ def test_data_parallel_step_averages_gradients_gloo():
 def test_fp16_emulation_explains_the_mixed_policy_error(oracle, golden_ckpt):
     """oracle.train_oracle's mixed_float16 emulation (fp16 operands and stash, row-scaled fp16 gradient operands, fp16 D
     carrying the loss scale -- where csrc/mlp_f16x3.hip FAST+STASH, mlp_bwd_f16x3.hip FAST and gemm_atb_f16 round):
-      * its forward is the numpy emulation of the single-pass render mode (oracle.mlp_forward_fp16) to float rounding;
+      * its forward is the numpy emulation of the stash forward's arithmetic (oracle.mlp_forward_fp16_train) to float rounding;
       * against the float64 graph it shows, by itself, the distances the GPU trainer has under that policy
         (tests/test_gpu_train.py: 1.1e-1 of max|g| for the coarse network at alpha 1; at the reference's alpha 0.05
         1.5e-2 without and 3.4e-1 with the sampler term, whose inverse-CDF interpolation has gains of 1e5) -- so those
@@ -206,7 +206,7 @@ def test_fp16_emulation_explains_the_mixed_policy_error(oracle, golden_ckpt):
     pts = rng.uniform(-1, 1, (200, 3)).astype(np.float32)
     dirs = rng.uniform(-1, 1, (200, 3)).astype(np.float32)
     xe, de = oracle.positional_encoding_for_xyz(pts, 5), oracle.positional_encoding_for_views(dirs, 4)
-    want = oracle.mlp_forward_fp16(oracle.unpack_blob(bc), xe, de, 0.05)
+    want = oracle.mlp_forward_fp16_train(oracle.unpack_blob(bc), xe, de, 0.05)     # rounds where mlp_f16x3.hip FAST rounds
     got = T._mlp16(T.blob_to_params(bc), torch.tensor(xe, dtype=torch.float64), torch.tensor(de, dtype=torch.float64),
                    0.05, 32768.0).detach().numpy()
     assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
