@@ -578,7 +578,7 @@ def main():
                                                                       "flops": "3 x forward GEMM flops"})},
                  "roofline": dict(hbm_view(e_tr, "train_step_f32", 4),
                                   kernel="whole step: mlp_f16x3_stash_kernel (fused forward) + mlp_bwd_f16x3[_dx]_kernel "
-                                         "(fused data-gradient chain) + gemm_atb_h (weight gradients, batched per pass), "
+                                         "(fused data-gradient chain, pair16 gradient buffers) + gemm_atb_p (weight gradients, batched per pass; the sigma head rides in layer 8's), "
                                          "all 3-pass split-fp16 MFMA with fp32 accumulation",
                                   mfma_view={"achieved": tf_tr, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
                                              "frac": tf_tr / PEAK_TFLOPS["f16x3"], "frac_vs_fp32_matrix_peak": tf_tr / PEAK_TFLOPS["f32"],
