@@ -92,14 +92,17 @@ def main():
                 o["wait_any_frac"] = a.get("SQ_WAIT_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
                 o["wait_inst_frac"] = a.get("SQ_WAIT_INST_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
             if a.get("SQ_BUSY_CYCLES"):
-                o["lds_bank_conflict_per_busy_cycle"] = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_BUSY_CYCLES"]
-            if lds.get("SQ_LDS_IDX_ACTIVE") and lds.get("SQ_BUSY_CYCLES"):
+                o["lds_bank_conflict_per_sq_busy_cycle_r3_quotient"] = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_BUSY_CYCLES"]
+            if lds.get("SQ_LDS_IDX_ACTIVE") and lds.get("GRBM_GUI_ACTIVE"):
                 d = {k: sum(v) / len(v) for k, v in lds.items()}
-                # SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count per-CU LDS-array cycles summed over the chip's SQs;
-                # SQ_BUSY_CYCLES is summed the same way: the quotient is the LDS array's busy share of the launch
-                o["lds_array_busy_frac"] = d["SQ_LDS_IDX_ACTIVE"] / d["SQ_BUSY_CYCLES"]
-                o["lds_conflict_share_of_lds_busy"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
-                o["lds_bank_conflict_per_busy_cycle"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_BUSY_CYCLES"]
+                # SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT are LDS-array cycles summed over the chip's 256 CUs (checked against the
+                # instruction mix of gemm_atb_p: 12 ds_read_b128 + 8 ds_write_b64 per wave and step); GRBM_GUI_ACTIVE / 8 is the
+                # launch's length in cycles.  SQ_BUSY_CYCLES sums over ~31 units, NOT 256: round 3's "conflicts per busy cycle"
+                # (kept below under its old name for comparison) overstates the per-CU share by 8x.
+                dc = d["GRBM_GUI_ACTIVE"] / 8.0
+                o["lds_array_busy_frac_per_cu"] = d["SQ_LDS_IDX_ACTIVE"] / 256.0 / dc
+                o["lds_bank_conflict_frac_of_cycles_per_cu"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / 256.0 / dc
+                o["sq_busy_cycles_units"] = d["SQ_BUSY_CYCLES"] / dc
             if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
                 o["hbm_bytes_per_launch"] = (2.0 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0
                 o["hbm_tb_per_s"] = o["hbm_bytes_per_launch"] / t / 1e12
