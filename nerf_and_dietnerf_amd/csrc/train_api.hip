@@ -347,7 +347,8 @@ int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     return 0;
 }
 
-void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
+// -> true if the GEMM also produced the weight gradient of head `sig_layer` (else the caller launches that head by itself)
+bool wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, const float* G, int ldg, int Ncols,
            int n_src_off, long long Mp, const unsigned* gmax = nullptr, WgradQueue* q = nullptr,
            const uint16_t* g_rs = nullptr /* pair16: G's row factors */,
            int sig_layer = -1 /* this GEMM also produces the weight gradient of head `sig_layer` (input = A) from t->dsig */) {
@@ -374,7 +375,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
     if (q && q->open && wide && reduce_grad_is_wide(r) && q->gemm.n < kWgradBatchMax) {
         q->gemm.e[q->gemm.n++] = g;               // slabs and partial regions are laid out by wgrad_flush
         q->red.e[q->red.n++] = r;
-        return;
+        return false;
     }
     const int n_splits = (int)((Mp + rps - 1) / rps);
     // the sigma head rides in this GEMM (gemm_atb_p / gemm_atb_f16, 128-wide tile): its slab sums land behind this GEMM's
@@ -399,6 +400,7 @@ void wgrad(nerf_ctx* c, TrainState* t, TNet& n, int l, const float* A, int lda, 
         rs.accumulate = t->acc_grads ? 1 : 0;
         launch_reduce_grad(rs, c->stream);
     }
+    return sig;
 }
 
 void dgrad(nerf_ctx* c, const float* G, int ldg, int Kg, const float* Wrows, int ldb, int Nout, const float* H, int ldh,
@@ -480,7 +482,8 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
             wgrad(c, t, n, 9, H9, ldh9, Graw, 4, 4, 0, Mp);
             // the sigma head (layer 10: input C8 = [h8 | dir_enc], gradient column 3 of Graw) rides in layer 8's GEMM, which
             // stages C8 anyway -- no second pass over that buffer
-            wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0), nullptr, RS(8), 10);
+            if (!wgrad(c, t, n, 8, C8, kLdC8, b.d_ptr[8], ldh9, 128, 0, Mp, GM(0), nullptr, RS(8), 10))
+                wgrad(c, t, n, 10, C8, kLdC8, Graw, 4, 4, 3, Mp);      // (a build without the by-product path: -DNERF_PAIR16=0, float32 policy)
             wq.open = t->wgrad_wide;
         }
         const int g0 = xyz ? 1 : 0;                      // gmax group of D_l is g0 + 8 - l
