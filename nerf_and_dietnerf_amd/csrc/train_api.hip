@@ -60,6 +60,16 @@ struct TrainState {
     TPass pass[2];
     DevBuf Ga, Gb, G9, Graw, dA0, partial, d_rgb, d_wext, d_zf, tgt, o, d, u_c, u_f, scal, gmax;
     DevBuf dsig;                    // (Mp) column 3 of Graw as a vector, written by the fused backward chain (GemmAtb::sig_g)
+    // The fine pass's batched weight-gradient launch on a second stream, beside the sampler / compositing backward and the coarse
+    // pass's backward chain (default; NERF_TRAIN_OVERLAP=0 keeps one stream).  Its slab sums live in their own buffer, each pass
+    // has its own max|D| slots, and the main stream joins before anything reads the fine network's gradient blob.  Both big
+    // kernels want a whole CU per workgroup, so this is tail filling, not co-residency: -1.2 % on a mixed_float16 step, +-0
+    // under the float32 policy; bit-identical results (tests/test_gpu_train.py::test_side_stream_...).
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
+    DevBuf partial_side;
     bool wgrad_f16 = false;         // weight gradients on the fp16 matrix cores (gemm_atb_h), else exact fp32 MFMA
     bool dgrad_f16 = false;         // data gradients on the fp16 matrix cores (gemm_abt_h)
     bool wgrad_wide = true;         // 256 x 256 tile for the 256-wide layers' weight gradients
@@ -314,9 +324,31 @@ size_t wgrad_batch_floats(const WgradQueue& q, int splits) {
     return off;
 }
 
-int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
+int join_side(nerf_ctx* c, TrainState* t) {       // the main stream waits for the side stream's weight gradients
+    if (t->side_pending) {
+        HIP_OK(hipStreamWaitEvent(c->stream, t->ev_join, 0));
+        t->side_pending = false;
+    }
+    return 0;
+}
+
+int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp, bool on_side = false) {
     q.open = false;
     if (q.gemm.n == 0) return 0;
+    hipStream_t st = c->stream;
+    DevBuf* pb = &t->partial;
+    if (on_side) {
+        if (!t->side) {
+            HIP_OK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        }
+        if (int r = join_side(c, t)) return r;         // (one launch in flight on the side stream at a time)
+        HIP_OK(hipEventRecord(t->ev_fork, c->stream));  // everything the GEMM reads has been enqueued on the main stream
+        HIP_OK(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+        st = t->side;
+        pb = &t->partial_side;
+    }
     int units = 0;
     for (int e = 0; e < q.gemm.n; ++e) units += (q.gemm.e[e].Kp + 255) / 256 * ((q.gemm.e[e].Nw + 255) / 256);
     // one 512-thread workgroup per CU, workgroups dealt round-robin to the 8 XCDs: a multiple of 8 slabs per layer such
@@ -329,21 +361,25 @@ int wgrad_flush(nerf_ctx* c, TrainState* t, WgradQueue& q, long long Mp) {
     const int splits = (int)((Mp + rps - 1) / rps);
     // the slab count follows the device's CU count: grow the partial-sum buffer to what THIS launch lays out (a device with
     // more CUs, a larger batch of layers) instead of trusting the size the per-layer launches were given
-    if (int r = ensure(c, t->partial, wgrad_batch_floats(q, splits) * sizeof(float))) { q.gemm.n = q.red.n = 0; return r; }
+    if (int r = ensure(c, *pb, wgrad_batch_floats(q, splits) * sizeof(float))) { q.gemm.n = q.red.n = 0; return r; }
     size_t off = 0;
     for (int e = 0; e < q.gemm.n; ++e) {
         GemmAtb& g = q.gemm.e[e];
         g.rows_per_split = (int)rps;
-        g.partial = (float*)t->partial.p + off;
+        g.partial = (float*)pb->p + off;
         q.red.e[e].partial = g.partial;
         q.red.e[e].splits = splits;
         off += (size_t)splits * (g.Kp + 1) * g.Nw;
     }
-    if (t->mixed) launch_gemm_atb_f16_batch(q.gemm, c->stream, true);
-    else if (q.gemm.e[0].g_rs) launch_gemm_atb_p_batch(q.gemm, c->stream, true);     // (one format per trainer: all entries agree)
-    else launch_gemm_atb_h_batch(q.gemm, c->stream, true);
-    launch_reduce_grad_batch(q.red, c->stream);
+    if (t->mixed) launch_gemm_atb_f16_batch(q.gemm, st, true);
+    else if (q.gemm.e[0].g_rs) launch_gemm_atb_p_batch(q.gemm, st, true);     // (one format per trainer: all entries agree)
+    else launch_gemm_atb_h_batch(q.gemm, st, true);
+    launch_reduce_grad_batch(q.red, st);
     q.gemm.n = q.red.n = 0;
+    if (on_side) {
+        HIP_OK(hipEventRecord(t->ev_join, t->side));
+        t->side_pending = true;
+    }
     return 0;
 }
 
@@ -444,7 +480,7 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     const bool dx = d_z != nullptr;
     // gm[k]: bits of max|G| of the gradient buffer produced k-th in this pass (scale of the split-fp16 weight gradient)
     // exact-fp32 weight gradients need no scale (but the fused chain always reports its maxima)
-    unsigned* gm = t->wgrad_f16 || t->fused_backward ? (unsigned*)t->gmax.p : nullptr;
+    unsigned* gm = t->wgrad_f16 || t->fused_backward ? (unsigned*)t->gmax.p + (size_t)which * 16 * 64 : nullptr;   // per pass
     if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
     auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
     auto DS = [&](int l) -> const TLayer* { return t->dgrad_f16 && gm ? &n.L[l] : nullptr; };   // pre-split W of layer l
@@ -499,7 +535,8 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
         const size_t xyz_off = (size_t)32 * 256;
         const float* c4_xyz = t->mixed ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(C4) + xyz_off) : C4 + xyz_off;
         wgrad(c, t, n, 0, c4_xyz, kLdC4, b.d_ptr[0], ldh, 256, 0, Mp, GM(g0 + 8), &wq, RS(0));
-        if (int r = wgrad_flush(c, t, wq, Mp)) return r;
+        // the fine pass's batched launch can run beside the coarse pass's backward (which reads none of its operands)
+        if (int r = wgrad_flush(c, t, wq, Mp, t->overlap && which == 1 && !t->acc_grads)) return r;
         if (dx) {
             if (!n.bdx) return fail("internal: the sampler term needs the backward stream with encoding tiles");
             launch_pe_bwd(b.dx_ptr[0], b.dx_ptr[1], o, dirs, (const float*)p.z.p, d.N, d.S, d_z, c->stream, true);
@@ -599,7 +636,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         r |= ensure(c, t->macc, 4 * sizeof(double));
         if (!r) HIP_OK(hipMemsetAsync(t->macc.p, 0, 4 * sizeof(double), c->stream));
     }
-    r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
+    r |= ensure(c, t->gmax, 2 * 16 * 64 * sizeof(unsigned));
     if (r) return r;
     float* scal = (float*)t->scal.p;
     float* Graw = (float*)t->Graw.p;
@@ -636,6 +673,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
     launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, d_rgb,
                          through_sampler ? (const float*)t->d_wext.p : nullptr, Graw, nullptr, c->stream);
     if (int q = backward_pass(c, t, 0, dc, o, d, nullptr)) return q;
+    if (int q = join_side(c, t)) return q;
     if (t->mixed) {
         // LossScaleOptimizer: unscale, test for Inf/NaN; the verdict is taken on the device (opt_verdict_kernel) and gates
         // this step's Adam update.  (The per-sample scaling of the backward chain makes the products themselves
@@ -705,7 +743,7 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     r |= ensure(c, t->z_new, (fine ? N * (long long)Sf : 1) * f);
     r |= ensure(c, t->d_zm, (fine ? df.M : 1) * f);
     r |= ensure(c, t->zero_rgb, N * 3 * f);
-    r |= ensure(c, t->gmax, 16 * 64 * sizeof(unsigned));
+    r |= ensure(c, t->gmax, 2 * 16 * 64 * sizeof(unsigned));
     if (t->mixed) {
         r |= ensure(c, t->d_rgb, N * 3 * f);
         if (accumulate)
@@ -778,6 +816,7 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     }
     t->acc_grads = false;
     if (q) return q;
+    if (int qj = join_side(c, t)) return qj;
     if (t->mixed) {
         float* g[2]; const float* add[2]; int n = 0;
         for (int w = 0; w < 2; ++w)
@@ -851,6 +890,10 @@ void train_free(nerf_ctx* c) {
         free_buf(p.masks); free_buf(p.dxa); free_buf(p.dxb); free_buf(p.rs);
         for (DevBuf& b : p.D) free_buf(b);
     }
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    free_buf(t->partial_side);
     DevBuf* bs[] = {&t->Ga, &t->Gb, &t->G9, &t->Graw, &t->dsig, &t->dA0, &t->partial, &t->d_rgb, &t->d_wext, &t->d_zf, &t->tgt,
                     &t->o, &t->d, &t->u_c, &t->u_f, &t->scal, &t->gmax, &t->z_new, &t->d_zm, &t->zero_rgb, &t->opt,
                     &t->gsave[0], &t->gsave[1], &t->macc};
@@ -927,6 +970,9 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     // for the layer-by-layer GEMMs; it reads the forward's mask records, so it needs the fused forward
     const char* bw = getenv("NERF_TRAIN_BACKWARD");
     t->fused_backward = t->fused_forward && t->dgrad_f16 && !(bw && strcmp(bw, "layers") == 0);
+    // the fine pass's batched weight-gradient launch on a second stream (see TrainState::overlap) unless NERF_TRAIN_OVERLAP=0
+    const char* ov = getenv("NERF_TRAIN_OVERLAP");
+    t->overlap = !(ov && strcmp(ov, "0") == 0);
     t->ldh = 256; t->ldh9 = 128;
     // the fused forward writes fragment-major buffers that only the fused backward and the weight-gradient kernels read:
     // both fused or neither (NERF_TRAIN_BACKWARD=layers, NERF_TRAIN_WGRAD / NERF_TRAIN_DGRAD=fp32 select the layer-wise

@@ -928,6 +928,32 @@ def test_fp16_core_trainer_equals_exact_fp32_trainer_at_full_size(oracle, golden
         print("\n[fp16-core vs exact-fp32 trainer, 1024 rays x 192] " + "\n    ".join(lines))
 
 
+@pytest.mark.parametrize("policy", ["float32", "mixed_float16"])
+def test_side_stream_weight_gradients_are_result_preserving(oracle, golden_ckpt, policy, monkeypatch):
+    """By default the fine pass's batched weight-gradient launch runs on a second stream beside the coarse pass's backward
+    (own slab-sum buffer, per-pass max|D| slots, joined before anything reads the fine gradient blob); NERF_TRAIN_OVERLAP=0
+    keeps one stream.  A selector, not a numerics switch: gradients, loss and the weights after three Adam steps must be
+    bit-identical either way."""
+    p = _problem(oracle, golden_ckpt, n=64, sc=8, sf=8, seed=5)
+    o, d, rng = _rays(oracle, 512, 23, hw=32)
+    tgt = rng.random((512, 3), dtype=np.float32)
+    got = {}
+    for ov in ("0", "1"):
+        monkeypatch.setenv("NERF_TRAIN_OVERLAP", ov)
+        ctx = _ctx(p)
+        ctx.train_begin(5e-4, mixed_float16=policy == "mixed_float16")
+        m, gc, gf = ctx.train_gradients(o, d, tgt, 64, 128, seed=11)
+        for i in range(3):
+            ctx.train_step(o, d, tgt, 64, 128, seed=20 + i, want_metrics=False)
+        got[ov] = (m["loss"], gc.copy(), gf.copy(), ctx.get_weights(0).copy(), ctx.get_weights(1).copy())
+        ctx.close()
+    monkeypatch.delenv("NERF_TRAIN_OVERLAP", raising=False)
+    a, b = got["0"], got["1"]
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("n_angles", [0, 1])
 def test_backward_through_render_and_mixed_policy_for_the_other_network_variants(oracle, n_angles, capsys):
     """The two less common network variants on the fused trainer (round 3: n_angles = 0 has its own kernels; n_angles = 1
