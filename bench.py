@@ -49,7 +49,7 @@ def sphere_matrix(radius, x_rot, y_rot, z_rot):
     return (rz @ (ry @ (rx @ t))).astype(np.float32)
 
 
-def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
+def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0, gpu_frame=None):
     """Oracle ("port") on the host cores, on a bounded sample of the same frame."""
     from oracle import nerf_oracle as O
     # the GPU box shows every host core but a 1-GPU job owns a 16-core share: pin BLAS to that
@@ -68,18 +68,26 @@ def cpu_baseline(blob_c, blob_f, c2w, seconds_budget=20.0):
         uc = O.philox_uniform(0, pick.astype(np.uint64), SC, 0)
         uf = O.philox_uniform(0, pick.astype(np.uint64), SF, 1)
         t0 = time.perf_counter()
-        O.render(coarse, fine, orig[pick], dirs[pick], NEAR, FAR, uc, uf)
-        return time.perf_counter() - t0
+        out = O.render(coarse, fine, orig[pick], dirs[pick], NEAR, FAR, uc, uf)
+        return time.perf_counter() - t0, pick, out[0]
 
-    t_small = run(256)                                   # calibration (also warms BLAS threads)
+    t_small, _, _ = run(256)                             # calibration (also warms BLAS threads)
     n = int(min(16384, max(512, 256 * seconds_budget / max(t_small, 1e-3))))
     n = (n // 256) * 256
-    t = run(n)
+    t, pick, rgb = run(n)
     if limiter is not None:
         limiter.restore_original_limits()
+    # the oracle as the CHECKER of the measured path (never the thing measured): the device frame of seed 0 -- the very
+    # draws the oracle made above, Philox keyed by (seed, global ray index) -- against the oracle's rays
+    parity = None
+    if gpu_frame is not None:
+        dev = np.asarray(gpu_frame(0)).reshape(-1, 3)[pick]
+        err = float(np.abs(dev - rgb).max())
+        parity = {"max_abs_rgb_vs_oracle": err, "rays": int(n), "bar": 1e-4, "ok": bool(err <= 1e-4),
+                  "note": "the timed mode's frame of seed 0 against the CPU oracle on the same rays, weights and draws"}
     return {"value": n / t, "unit": "rays/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} rays of the same 256x256 frame (64+128 samples), numpy fp32 + OpenBLAS, "
-                      f"{t:.1f} s; CPU restatement of the reference algorithm (not TensorFlow)"}
+                      f"{t:.1f} s; CPU restatement of the reference algorithm (not TensorFlow)"}, parity
 
 
 def csrc_sha16():
@@ -716,7 +724,12 @@ def main():
         if xyz_only is not None:
             out["xyz_only"] = xyz_only
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(blob_c, blob_f, c2w)
+            model.set_weights(blob_c, blob_f)               # (the training measurement above moved them)
+            model.ctx.set_precision(args.precision)
+            frame0 = lambda sd: model.render_image(c2w, FOV, H, W, seed=sd, rgb_only=True)[0]     # noqa: E731
+            out["cpu_baseline"], parity = cpu_baseline(blob_c, blob_f, c2w, gpu_frame=frame0)
+            if parity is not None:
+                out["parity_check"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
