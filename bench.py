@@ -299,19 +299,57 @@ def main():
         return rgb
 
     gather_check = None
+    c_check_hung = False          # a worker thread is still blocked inside RCCL: leave through os._exit at the end
     # (also under the one-GPU rehearsal -- BENCH_BACKEND=gloo with NERF_RCCL_LIB naming tests/stub_rccl.c's stand-in, the only
     # way two ranks can share a device -- so that this check itself has run before the driver's first real N > 1 launch)
     if world > 1 and (backend == "nccl" or os.environ.get("NERF_RCCL_LIB")):
         # the two assemblies of the frame (torch collective vs the library's own ncclAllGather) must agree bit for bit.
         # A mismatch fails the run loudly; a C-level communicator that cannot be created (it is a second RCCL
         # communicator beside torch's) is reported and the run goes on with the torch collective.
-        try:
-            if not c_gather:
-                model.ctx.comm_init_from_torch()
-            a_img = model.ctx.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=12345, device_out=True)
-        except Exception as e:                                   # noqa: BLE001
+        # The second communicator has never met real peers on this pool (one-GPU boxes): its creation and first collective run in
+        # a worker thread under a wall-clock limit (BENCH_C_CHECK_TIMEOUT seconds, default 120), so that a hang there costs the
+        # cross-check, not the run -- the timed region below uses torch's collective unless --c-gather asks otherwise.
+        # The check runs on a context of ITS OWN (same weights, own stream): a ctx is single-caller, and the main thread must be
+        # free to go on with `model.ctx` if the worker never comes back.
+        box = {}
+        chk = model.ctx
+        if not c_gather:
+            chk = N.Context(near=NEAR, far=FAR, n_angles=2, precision=args.precision, device=dev_index)
+            chk.load_weights(0, blob_c); chk.load_weights(1, blob_f)
+
+        def c_level_frame(uid):
+            try:
+                if os.environ.get("BENCH_C_CHECK_TEST_HANG") == "1":     # test hook: a call that never returns (touches nothing)
+                    threading.Event().wait()
+                torch.cuda.set_device(dev_index)                 # (torch's current device is per thread)
+                if uid is not None:
+                    chk.comm_init(uid, rank, world)
+                img_c = chk.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=12345, device_out=True)
+                chk.synchronize()
+                torch.cuda.synchronize()
+                box["img"] = img_c
+            except Exception as e:                               # noqa: BLE001
+                box["err"] = e
+
+        uid = None
+        if not c_gather:                                         # (--c-gather created the communicator above)
+            ids = [chk.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            uid = ids[0]
+        worker = threading.Thread(target=c_level_frame, args=(uid,), daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("BENCH_C_CHECK_TIMEOUT", "120")))
+        a_img = box.get("img")
+        if worker.is_alive():
             if c_gather:
-                raise
+                raise SystemExit(f"rank {rank}: the library's RCCL communicator did not come up within the time limit")
+            c_check_hung = True
+            a_img = None
+            gather_check = "c-level communicator / first ncclAllGather did not return within the time limit; torch all-gather only"
+        elif "err" in box:
+            if c_gather:
+                raise box["err"]
+            e = box["err"]
             a_img = None
             gather_check = f"c-level communicator unavailable ({type(e).__name__}: {e}); torch all-gather only"
         # every rank takes the same branch below (the comparison contains a collective): all or none
@@ -733,6 +771,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if c_check_hung:          # do not run RCCL's teardown beside a call that never returned
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
