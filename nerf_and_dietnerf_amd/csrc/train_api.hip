@@ -481,7 +481,8 @@ int backward_pass(nerf_ctx* c, TrainState* t, int which, const PassDims& d, cons
     // gm[k]: bits of max|G| of the gradient buffer produced k-th in this pass (scale of the split-fp16 weight gradient)
     // exact-fp32 weight gradients need no scale (but the fused chain always reports its maxima)
     unsigned* gm = t->wgrad_f16 || t->fused_backward ? (unsigned*)t->gmax.p + (size_t)which * 16 * 64 : nullptr;   // per pass
-    if (gm) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
+    // (the max|D| slots feed the split-fp16 weight gradients' scale; gemm_atb_f16 reads none: no reset under mixed_float16)
+    if (gm && !t->mixed) HIP_OK(hipMemsetAsync(gm, 0, 16 * 64 * sizeof(unsigned), c->stream));
     auto GM = [&](int k) -> unsigned* { return gm ? gm + 64 * k : nullptr; };
     auto DS = [&](int l) -> const TLayer* { return t->dgrad_f16 && gm ? &n.L[l] : nullptr; };   // pre-split W of layer l
     if (t->frag && !(n.bstream && n.fcst && p.masks.p && gm))

@@ -20,9 +20,16 @@ if [ $part = a ]; then
   cd /tmp && export TMPDIR=/tmp
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_r4_bench -o b --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --quick > $O/prof_r4_bench.log 2>&1 || exit 1
   echo "bench trace ok"
+  # per-kernel times of a training step on ONE stream (NERF_TRAIN_OVERLAP=0: with the fine pass's weight-gradient launch on its
+  # second stream the overlapped kernels' durations stretch and their sum says nothing); the step itself is timed both ways below
+  export NERF_TRAIN_OVERLAP=0
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_r4_train -o t --output-format csv -- python3 $R/tools/train_bench.py 8 > $O/prof_r4_train.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_r4_mixed -o m --output-format csv -- python3 $R/tools/train_bench.py 8 4096 mixed > $O/prof_r4_mixed.log 2>&1 || exit 1
   grep train_step $O/prof_r4_train.log $O/prof_r4_mixed.log
+  for ov in 0 1; do for pol in fp32 mixed; do
+    NERF_TRAIN_OVERLAP=$ov timeout -k 10 120 python3 $R/tools/train_bench.py 30 4096 $pol 2>&1 | grep train_step | sed "s|^|[second stream: $ov] |"
+  done; done | tee $O/r4_train_step_both_ways.txt
+  unset NERF_TRAIN_OVERLAP
   for mode in f16x3 f16; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMCSET -d $O/pmc4_${mode}a -o a --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --quick --precision $mode > $O/pmc4_${mode}a.log 2>&1 || exit 1
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc4_${mode}b -o b --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --quick --precision $mode > $O/pmc4_${mode}b.log 2>&1 || exit 1
