@@ -97,6 +97,38 @@ def test_gradients_coarse_and_fine(oracle, golden_ckpt, sampler_gradient, alpha)
     ctx.close()
 
 
+@pytest.mark.parametrize("policy", ["float32", "mixed_float16"])
+def test_gradients_with_a_wide_dynamic_range_between_rays(oracle, golden_ckpt, policy, capsys):
+    """The weight gradient sums over sample rows whose loss gradients differ by many orders of magnitude.  The float32 policy's
+    gradient buffers carry one power-of-two scale PER ROW (pair16: the backward chain's packed operand + a per-row factor that
+    gemm_atb_p applies while staging; rows far below the largest are dropped as an fp32 sum drops them), so the case to pin is
+    a batch where a few rays dominate: targets 300x off for two rays (20x under mixed_float16, whose fp16 gradient buffers carry
+    the loss scale), the rendered colour itself for a third of the rays (loss gradients orders of magnitude below the rest),
+    ordinary for the others.  Same bars as the ordinary batch (alpha = 1: the smooth network)."""
+    from oracle import train_oracle as T
+    p = _problem(oracle, golden_ckpt, n=48, sc=16, sf=24, seed=9)
+    ctx = _ctx(p, leaky_relu_alpha=1.0)
+    rgb = ctx.render(p["o"], p["d"], p["sc"], p["sf"], p["u_c"], p["u_f"])[0]
+    tgt = p["tgt"].copy()
+    mixed = policy == "mixed_float16"
+    tgt[::3] = rgb[::3]                      # (render()'s colour: the trainer's two passes land within ~1e-2 of it)
+    tgt[1] = 20.0 if mixed else 300.0
+    tgt[16] = -15.0 if mixed else -250.0
+    ctx.train_begin(5e-4, mixed_float16=mixed)
+    m, gc, gf = ctx.train_gradients(p["o"], p["d"], tgt, p["sc"], p["sf"], p["u_c"], p["u_f"])
+    r = T.train_gradients(p["bc"], p["bf"], p["o"], p["d"], tgt, p["near"], p["far"], p["u_c"], p["u_f"], alpha=1.0,
+                          fp16_loss_scale=32768.0 if mixed else None)
+    ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
+    with capsys.disabled():
+        print(f"\n[{policy}, two rays far off, a third of the rays at their own rendered colour] vs "
+              f"{'the fp16-emulating' if mixed else 'float64'} autograd: coarse {ec:.2e}, fine {ef:.2e} of max|g|", end="")
+    assert np.isfinite(gc).all() and np.isfinite(gf).all()
+    assert abs(m["loss"] - r["loss"]) <= (2e-3 if mixed else 2e-6) * r["loss"]
+    tol = 2e-2 if mixed else 2e-4
+    assert ec <= tol and ef <= tol, (ec, ef)
+    ctx.close()
+
+
 def test_gradients_device_rng_and_odd_sizes(oracle, golden_ckpt):
     """u = NULL: jitter and inverse-CDF draws from the on-device Philox (same counters in the forward sampler
     and in its backward); N*S not a multiple of the 128-row GEMM tile; n_angles = 1 network."""
