@@ -239,6 +239,170 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- variant 2: 16-row steps in a FOUR-slot ring (96 KB in flight instead of 64), one barrier per 16 rows, the slab's row
+// factors converted once into an LDS table (no vector-memory instruction the compiler knows about inside the loop) ----
+constexpr int kSlotBytes = 32 * 1024;              // A 16 KB | G 16 KB of one 16-row step
+constexpr int kR4Ftab = 4 * kSlotBytes;            // fp16 factors of the whole slab (<= 8192 rows)
+constexpr int kR4MaxRows = 8192;
+constexpr int kR4LdsBytes = kR4Ftab + kR4MaxRows * 2;
+
+template <int PASSES>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_ring4_kernel(const Args a) {
+    const int per_entry = a.splits;
+    const int ent = blockIdx.x / per_entry, split = blockIdx.x % per_entry;
+    if (ent >= a.n_entries) return;
+    const Entry E = a.e[ent];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wk = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const long long row0 = (long long)split * a.rows_per_split;
+    const int hsteps = (int)(a.rows_per_split / 16);           // 16-row steps
+
+    for (int r = t; r < (int)a.rows_per_split; r += 512) {
+        const float f = fminf(__uint_as_float((uint32_t)E.rs[row0 + r] << 16) * a.gscale, 32768.0f);
+        reinterpret_cast<_Float16*>(smem + kR4Ftab)[r] = (_Float16)f;
+    }
+    const int d_rq = lane >> 4, d_g = (lane >> 3) & 1, d_h = (lane >> 2) & 1, d_q = lane & 3;
+    const uint32_t d_lane_off = (uint32_t)((2 * wave + d_g) * 2048 + d_h * 512 + (4 * d_rq + d_q) * 16);
+    // piece j (0..3) of this wave's share of 16-row step hs: operand j / 2, plane j % 2
+    auto dma_one = [&](int hs, auto jc) {
+        constexpr int j = decltype(jc)::value, op = j >> 1, pl = j & 1;
+        const size_t blk = (size_t)(row0 / kStepRows + (hs >> 1)) * kOpBytes;
+        const uint64_t bv = (uint64_t)((op ? E.G : E.A) + blk);
+        const char* base = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv));
+        dma_piece(base, d_lane_off + pl * 1024 + (hs & 1) * 256,
+                  (uint32_t)((hs & 3) * kSlotBytes + op * (kSlotBytes / 2) + (wave * 2 + pl) * 1024));
+    };
+    auto dma_all = [&](int hs) {
+        dma_one(hs, std::integral_constant<int, 0>{}); dma_one(hs, std::integral_constant<int, 1>{});
+        dma_one(hs, std::integral_constant<int, 2>{}); dma_one(hs, std::integral_constant<int, 3>{});
+    };
+    const int lane16 = lane & 15, tq = lane16 >> 2, tp = lane16 & 3, tg = (lane >> 4) & 1;
+    const uint32_t tr_lane = (uint32_t)((2 * lh) * 256 + tg * 128 + (tp & 1) * 64 + tq * 16 + 8 * (tp >> 1));
+    struct OpSet { u32x4 ah[4], al[4], gh[2], gl[2]; };
+    auto rd = [&](uint32_t off) -> u32x4 {
+        const s4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(uintptr_t)(off));
+        const s4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(uintptr_t)(off + 256));
+        const u32x2 x2 = __builtin_bit_cast(u32x2, x), y2 = __builtin_bit_cast(u32x2, y);
+        return u32x4{x2[0], x2[1], y2[0], y2[1]};
+    };
+    auto read_part = [&](OpSet& S, int hs, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t base = (uint32_t)((hs & 3) * kSlotBytes) + tr_lane;
+        const uint32_t ca = base + (uint32_t)((wk * 4 + i) * 2) * 1024;
+        S.ah[i] = rd(ca);
+        S.al[i] = rd(ca + 1024);
+        if constexpr (i < 2) {
+            const uint32_t cg = base + kSlotBytes / 2 + (uint32_t)((wn * 2 + i) * 2) * 1024;
+            S.gh[i] = rd(cg);
+            S.gl[i] = rd(cg + 1024);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+    float cs[2] = {0.f, 0.f};
+    auto scale = [&](OpSet& S, const u32x4& f) {
+        const h2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t wh = S.gh[q][d], wl = S.gl[q][d], wf = f[d];
+                const h2 gh2 = __builtin_bit_cast(h2, wh) * __builtin_bit_cast(h2, wf);
+                const h2 gl2 = __builtin_bit_cast(h2, wl) * __builtin_bit_cast(h2, wf);
+                S.gh[q][d] = __builtin_bit_cast(uint32_t, gh2);
+                S.gl[q][d] = __builtin_bit_cast(uint32_t, gl2);
+                if (wk == 0) {
+                    cs[q] = __builtin_amdgcn_fdot2(gh2, one2, cs[q], false);
+                    cs[q] = __builtin_amdgcn_fdot2(gl2, one2, cs[q], false);
+                }
+            }
+        }
+    };
+    auto mfma_part = [&](const OpSet& S, auto ic) {
+        constexpr int i = decltype(ic)::value;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const h8 ah = __builtin_bit_cast(h8, S.ah[i]), al = __builtin_bit_cast(h8, S.al[i]);
+            const h8 gh = __builtin_bit_cast(h8, S.gh[c]), gl = __builtin_bit_cast(h8, S.gl[c]);
+            if constexpr (PASSES == 3) {
+                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc[i][c], 0, 0, 0);
+                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[i][c], 0, 0, 0);
+            }
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[i][c], 0, 0, 0);
+        }
+    };
+    // one 16-row step: X holds step hs (read a step ago), Y receives step hs + 1, the DMA pieces of step hs + 3 go out between
+    // the MFMA groups.  (Past the slab's end: clamped block index -- valid memory, never used.)
+    auto half_step = [&](OpSet& X, OpSet& Y, u32x4& fx, u32x4& fy, int hs) {
+        // the next step's row factors (the table is static): issued FIRST, so that every later LDS wait covers it -- the compiler
+        // does not know this asm read, and a counted wait of its own for X's early parts would not include a read issued after them
+        const int hn = hs + 1 < hsteps ? hs + 1 : hsteps - 1;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fy) : "v"((uint32_t)(kR4Ftab + (hn * 16 + 8 * lh) * 2)) : "memory");
+        scale(X, fx);                              // (the compiler waits for X's reads here: they flew under the previous step's MFMAs)
+        // step hs + 1 has landed for this wave (the 4 pieces of hs + 2 may still fly); every read of slot hs - 1 has returned
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int h3 = hs + 3 < hsteps ? hs + 3 : hsteps - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_part(X, std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
+        read_part(Y, hs + 1, std::integral_constant<int, 0>{}); dma_one(h3, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_part(X, std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
+        read_part(Y, hs + 1, std::integral_constant<int, 1>{}); dma_one(h3, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_part(X, std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+        read_part(Y, hs + 1, std::integral_constant<int, 2>{}); dma_one(h3, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_part(X, std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
+        read_part(Y, hs + 1, std::integral_constant<int, 3>{}); dma_one(h3, std::integral_constant<int, 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    OpSet S0, S1;
+    if (hsteps > 0) {
+        dma_all(0);
+        dma_all(hsteps > 1 ? 1 : 0);
+        dma_all(hsteps > 2 ? 2 : hsteps - 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // step 0's four pieces have landed
+        __syncthreads();                                      // (also publishes the factor table)
+        read_part(S0, 0, std::integral_constant<int, 0>{}); read_part(S0, 0, std::integral_constant<int, 1>{});
+        read_part(S0, 0, std::integral_constant<int, 2>{}); read_part(S0, 0, std::integral_constant<int, 3>{});
+        u32x4 f0 = *reinterpret_cast<const u32x4*>(smem + kR4Ftab + (8 * lh) * 2), f1 = f0;
+        for (int hs = 0; hs < hsteps; hs += 2) {              // (hsteps is even: 32-row blocks)
+            half_step(S0, S1, f0, f1, hs);
+            half_step(S1, S0, f1, f0, hs + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const float ginv = 1.0f / a.gscale;
+    float* part = E.partial + (size_t)split * 257 * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = wn * 64 + c * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = wk * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                part[(size_t)k * 256 + n] = acc[i][c][r] * ginv;
+            }
+        }
+    if (wk == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v = cs[q] + __shfl_xor(cs[q], 32);
+            if (lh == 0) part[(size_t)256 * 256 + wn * 64 + q * 32 + li] = v * ginv;
+        }
+    }
+}
+
 // ---- host: plane8 packing of an (M x 256) matrix of (hi, lo) pairs ----
 static inline size_t plane8_off(long long row, int f, int plane) {     // byte offset of the HALF of feature f
     const long long blk = row / 32; const int j = (int)(row % 32);
@@ -299,6 +463,18 @@ int main() {
         printf("check (192 rows, 2 slabs): max |dW - ref| = %.3e of max|dW| %.3e (%.2e relative), bias row max error %.3e\n", worst, mx,
                worst / mx, wb);
         if (!(worst / mx < 1e-5)) { printf("FAILED\n"); return 1; }
+        // the four-slot ring variant must give the same sums (same products, same order per accumulator)
+        HIP_OK(hipFuncSetAttribute((const void*)wgrad_ring4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kR4LdsBytes));
+        HIP_OK(hipFuncSetAttribute((const void*)wgrad_ring4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kR4LdsBytes));
+        HIP_OK(hipMemset(dp, 0, p.size() * 4));
+        hipLaunchKernelGGL(wgrad_ring4_kernel<3>, dim3(splits), dim3(512), kR4LdsBytes, 0, a);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> p4(p.size());
+        HIP_OK(hipMemcpy(p4.data(), dp, p4.size() * 4, hipMemcpyDeviceToHost));
+        double d4 = 0;
+        for (size_t i = 0; i < p.size(); ++i) d4 = fmax(d4, fabs((double)p4[i] - (double)p[i]));
+        printf("check: four-slot ring variant vs the two-buffer variant: max difference %.3e\n", d4);
+        if (!(d4 <= 1e-6 * mx)) { printf("FAILED\n"); return 1; }
         hipFree(dA); hipFree(dG); hipFree(drs); hipFree(dp);
     }
     // ---------------- timing: the trainer's fine pass (8 layers x 524288 rows, 64 slabs per layer) ----------------
@@ -332,6 +508,20 @@ int main() {
             if (passes == 0) printf("(next line: 3 passes WITHOUT the DMA -- the compute side alone)\n");
             printf("%d MFMA pass(es): %8.1f us per launch (8 layers x 524288 rows): %.2f TB/s of operands  [gemm_atb_p<256> today: ~1730 us, 4.95 TB/s; 1-pass build 5.96 TB/s]\n",
                    passes, ms * 1e3, (double)opb * 2 * L / (ms * 1e-3) / 1e12);
+        }
+        for (int passes = 3; passes >= 1; passes -= 2) {
+            auto launch = [&]() {
+                if (passes == 3) hipLaunchKernelGGL(wgrad_ring4_kernel<3>, dim3(L * splits), dim3(512), kR4LdsBytes, 0, a);
+                else hipLaunchKernelGGL(wgrad_ring4_kernel<1>, dim3(L * splits), dim3(512), kR4LdsBytes, 0, a);
+            };
+            launch(); HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipEventRecord(e0));
+            const int reps = 5;
+            for (int i = 0; i < reps; ++i) launch();
+            HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
+            float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("four-slot ring, %d MFMA pass(es): %8.1f us per launch: %.2f TB/s of operands\n", passes, ms * 1e3,
+                   (double)opb * 2 * L / (ms * 1e-3) / 1e12);
         }
     }
     return 0;
