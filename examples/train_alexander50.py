@@ -10,7 +10,8 @@ BASELINE.json) with this library and prints the per-epoch PSNRs beside the ones 
 Differences to the recorded run, none of which this pipeline can remove: fresh Glorot initialisation and shuffling
 (different random streams than TensorFlow's), fp32 instead of the mixed_float16 policy, Pillow's JPEG decode.
 
-Usage: python examples/train_alexander50.py [epochs] [out.json]
+Usage: python examples/train_alexander50.py [epochs] [out.json] [float32|mixed_float16]
+(the third argument selects the policy; the reference recorded its run under mixed_float16 + LossScaleOptimizer)
 """
 import json
 import os
@@ -29,6 +30,7 @@ import nerf_and_dietnerf_amd as N
 def main():
     epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 95
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    policy = sys.argv[3] if len(sys.argv) > 3 else "float32"
     data = os.path.join(ROOT, "tests", "golden", "alexander50")
     images, poses, fov, near, far, _, _ = N.get_data_from_colmap(data)
     recorded = np.load(os.path.join(ROOT, "tests", "golden", "alexander50_recorded_psnrs.npy"))   # [test, train] x 95
@@ -40,7 +42,7 @@ def main():
     ren_cfg = {"n_render_samples_coarse": 64, "n_render_samples_fine": 128}
     model = N.NeRF(net_cfg, ren_cfg, near, far)
     model.set_weights(N.glorot_blob(0), N.glorot_blob(1))
-    model.compile(4.0e-4)
+    model.compile(4.0e-4, mixed_float16=policy == "mixed_float16")
     ds = N.prepare_ds(net_cfg["n_rays_in_batch_train"], poses[train_idx], images[train_idx], fov, model.ctx, seed=0)
     dev = torch.device("cuda", 0)
     tgt_test = torch.as_tensor(images[idx_test], device=dev)
@@ -62,11 +64,11 @@ def main():
         print(f"epoch {e:3d}  loss {hist['loss']:.5f}  test {p_test:6.2f} dB (recorded {rec[0]:6.2f})  "
               f"train view {p_train:6.2f} dB (recorded {rec[1]:6.2f})", flush=True)
     dt = time.perf_counter() - t0
-    print(f"{epochs} epochs x {len(ds)} steps in {dt:.1f} s ({dt / (epochs * len(ds)) * 1e3:.1f} ms per step incl. "
+    print(f"[{policy} policy] {epochs} epochs x {len(ds)} steps in {dt:.1f} s ({dt / (epochs * len(ds)) * 1e3:.1f} ms per step incl. "
           f"the two evaluation renders per epoch)")
     if out_path:
         with open(out_path, "w") as f:
-            json.dump({"epochs": rows, "seconds": dt, "steps_per_epoch": len(ds)}, f, indent=1)
+            json.dump({"policy": policy, "epochs": rows, "seconds": dt, "steps_per_epoch": len(ds)}, f, indent=1)
 
 
 if __name__ == "__main__":
