@@ -961,6 +961,41 @@ def test_fp16_core_trainer_equals_exact_fp32_trainer_at_full_size(oracle, golden
 
 
 @pytest.mark.parametrize("policy", ["float32", "mixed_float16"])
+def test_gradients_of_a_large_batch_equal_the_mean_of_its_halves(oracle, golden_ckpt, policy, capsys):
+    """A size-independent property at a size the CPU oracle cannot reach (8192 rays x (64 + 128) samples = 1.6 M sample rows, twice
+    the reference's batch): the loss is a mean over rays, so the gradients of the batch are the mean of the gradients of its two
+    4096-ray halves -- whatever slab counts, batched launches and buffer sizes the larger call picks."""
+    import torch
+    p = _problem(oracle, golden_ckpt, n=64, sc=8, sf=8, seed=2)            # only for weights / near / far
+    ctx = _ctx(p)
+    ctx.use_torch_stream()
+    ctx.train_begin(5e-4, mixed_float16=policy == "mixed_float16")
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(3)
+    o = torch.zeros((n, 4), device="cuda"); o[:, :3] = torch.tensor(oracle.get_sphere_matrix(1.0, -20, 30, 0)[:3, 3]); o[:, 3] = 1.0
+    d = torch.randn((n, 4), device="cuda", generator=g) * 0.2; d[:, 3] = 0.0
+    d[:, :3] -= o[:, :3]                                                      # towards the scene
+    tgt = torch.rand((n, 3), device="cuda", generator=g)
+    uc, uf = torch.rand((n, 64), device="cuda", generator=g), torch.rand((n, 128), device="cuda", generator=g)
+    host = lambda t: np.asarray(t.cpu() if hasattr(t, "cpu") else t, dtype=np.float64)      # noqa: E731
+    m, gc, gf = ctx.train_gradients(o, d, tgt, 64, 128, uc, uf)
+    gc, gf = host(gc), host(gf)
+    acc_c, acc_f, loss = np.zeros_like(gc), np.zeros_like(gf), 0.0
+    for k in range(2):
+        sl = slice(k * 4096, (k + 1) * 4096)
+        mk, c, f = ctx.train_gradients(o[sl], d[sl], tgt[sl], 64, 128, uc[sl], uf[sl])
+        acc_c += host(c) / 2; acc_f += host(f) / 2; loss += float(mk["loss"]) / 2
+    ec, ef = _relerr(gc, acc_c), _relerr(gf, acc_f)
+    with capsys.disabled():
+        print(f"\n[{policy}] 8192 rays in one call vs the mean of its halves: loss {float(m['loss']):.7f} / {loss:.7f}, "
+              f"gradients coarse {ec:.1e}, fine {ef:.1e} of max|g|", end="")
+    tol = 2e-5 if policy == "mixed_float16" else 2e-6
+    assert np.isfinite(gc).all() and np.isfinite(gf).all()
+    assert abs(float(m["loss"]) - loss) <= 1e-6 * loss and ec <= tol and ef <= tol
+    ctx.close()
+
+
+@pytest.mark.parametrize("policy", ["float32", "mixed_float16"])
 def test_side_stream_weight_gradients_are_result_preserving(oracle, golden_ckpt, policy, monkeypatch):
     """By default the fine pass's batched weight-gradient launch runs on a second stream beside the coarse pass's backward
     (own slab-sum buffer, per-pass max|D| slots, joined before anything reads the fine gradient blob); NERF_TRAIN_OVERLAP=0
