@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 4
+#define NERF_ABI_VERSION 5
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
 enum { NERF_MEM_HOST = 0, NERF_MEM_DEVICE = 1 };
@@ -203,6 +203,13 @@ int nerf_train_begin(nerf_ctx* ctx, const nerf_train_config* cfg);
 /* Packs the trained weights for the render path and frees optimizer state and activation buffers. */
 int nerf_train_end(nerf_ctx* ctx);
 int nerf_train_set_learning_rate(nerf_ctx* ctx, float learning_rate);
+/* ABI 5: the ray loss of nerf_train_step / nerf_train_gradients is coarse_mse_weight * MSE(coarse render) +
+ * fine_mse_weight * MSE(fine render).  (1, 1) -- the state nerf_train_begin leaves -- is NeRF.train_step
+ * (src/NeRF.py:151,157).  DietNeRF's train_step builds its ray loss differently (src/DietNeRF.py:160-170,
+ * `loss = loss_for_rays` BEFORE `loss_for_rays += <fine MSE>`, then `loss += loss_for_rays`): 2 * MSE(coarse) +
+ * MSE(fine) is what its tape differentiates -- (2, 1) here.  The weights act on the gradients and on the `loss` metric
+ * (and its running sum); psnr_coarse / psnr_fine stay the plain per-pass values.  Finite, >= 0. */
+int nerf_train_set_loss_weights(nerf_ctx* ctx, float coarse_mse_weight, float fine_mse_weight);
 /* mixed_float16 policy: the current loss scale, the optimizer steps applied and the steps skipped so far (1 / n / 0
  * under the fp32 policy).  Any pointer may be NULL. */
 int nerf_train_loss_scale(nerf_ctx* ctx, float* loss_scale, int64_t* steps_applied, int64_t* steps_skipped);

@@ -14,6 +14,7 @@ from .render import (Context, NeRF, NetHandle, default_context, get_rays_directi
 from .keras_h5 import load_nerf_checkpoint, read_keras_weights, save_nerf_checkpoint, write_keras_weights
 from .sharding import allreduce_mean, dist_world, gather_slabs, ray_slab, render_image_sharded
 from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
+from .dietnerf import DietNeRF
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
                        poses_avg, recenter_poses, spherify_poses)
 from .video import (get_c2w_matrices_between_2_c2w_with_stretch, get_path_c2w_matrices,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NERF_MI355_LIB") or os.path.join(_HERE, "lib", "libne
 NERF_NET_COARSE, NERF_NET_FINE = 0, 1
 NERF_MEM_HOST, NERF_MEM_DEVICE = 0, 1
 NERF_PRECISION_FP32, NERF_PRECISION_F16X3, NERF_PRECISION_F16 = 0, 1, 2
-NERF_ABI_VERSION = 4
+NERF_ABI_VERSION = 5
 
 
 class NerfConfig(C.Structure):
@@ -73,6 +73,7 @@ SYMBOLS = [
     ("nerf_train_begin", C.c_int, [_P, C.POINTER(NerfTrainConfig)]),
     ("nerf_train_end", C.c_int, [_P]),
     ("nerf_train_set_learning_rate", C.c_int, [_P, _F]),
+    ("nerf_train_set_loss_weights", C.c_int, [_P, _F, _F]),
     ("nerf_train_loss_scale", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_I64), C.POINTER(_I64)]),
     ("nerf_train_read_metric_sums", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     ("nerf_train_step", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _P, C.c_int]),

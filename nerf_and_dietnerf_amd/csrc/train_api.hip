@@ -77,6 +77,9 @@ struct TrainState {
     // L2-channel hot-spotting in round 2 and lost; the fused path's buffers are fragment-major now, frag_layout.h)
     int ldh = 256, ldh9 = 128;
     bool acc_grads = false;         // the running backward pass ADDS to the gradient blobs (nerf_train_render_gradients)
+    // ray loss = loss_w[0] * MSE(coarse) + loss_w[1] * MSE(fine) (nerf_train_set_loss_weights): 1, 1 is NeRF.train_step
+    // (src/NeRF.py:151,157); DietNeRF's ray loss counts the coarse term twice (src/DietNeRF.py:160-170)
+    float loss_w[2] = {1.f, 1.f};
     // mixed_float16 policy (src/ExecutionRun.py:220-221, src/NeRF.py:159-163): single-pass fp16 forward / data gradients
     // and the dynamic loss scale of Keras' LossScaleOptimizer
     bool mixed = false;
@@ -659,7 +662,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, (float*)pf.z.p, nullptr,
                           c->stream);
         if (int q = forward_pass(c, t, 1, df, o, d)) return q;
-        launch_mse((const float*)pf.rgb.p, tg, N, (const OptState*)t->opt.p, d_rgb, scal + 1, c->stream);
+        launch_mse((const float*)pf.rgb.p, tg, N, (const OptState*)t->opt.p, t->loss_w[1], d_rgb, scal + 1, c->stream);
         HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
         float* d_zf = through_sampler ? (float*)t->d_zf.p : nullptr;
         launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sf, d_rgb, nullptr,
@@ -669,7 +672,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
             launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, 0, d_zf,
                                   (float*)t->d_wext.p, c->stream);
     }
-    launch_mse((const float*)pc.rgb.p, tg, N, (const OptState*)t->opt.p, d_rgb, scal + 0, c->stream);
+    launch_mse((const float*)pc.rgb.p, tg, N, (const OptState*)t->opt.p, t->loss_w[0], d_rgb, scal + 0, c->stream);
     HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
     launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, d_rgb,
                          through_sampler ? (const float*)t->d_wext.p : nullptr, Graw, nullptr, c->stream);
@@ -682,7 +685,7 @@ int gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d, const 
         // skip-step behaviour.)
         launch_unscale_check(t->net[0].grad, fine ? t->net[1].grad : nullptr, t->nblob, (OptState*)t->opt.p, c->stream);
     }
-    launch_metrics_accum(scal, fine, (double*)t->macc.p, c->stream);
+    launch_metrics_accum(scal, fine, t->loss_w[0], t->loss_w[1], (double*)t->macc.p, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -838,7 +841,8 @@ int read_metrics(nerf_ctx* c, bool fine, float* metrics) {
     float h[2] = {0.f, 0.f};
     HIP_OK(hipMemcpyAsync(h, c->train->scal.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    metrics[0] = fine ? h[0] + h[1] : h[0];                            // src/NeRF.py:151,157
+    const float* lw = c->train->loss_w;                                // (1, 1: the products are exact)
+    metrics[0] = fine ? lw[0] * h[0] + lw[1] * h[1] : lw[0] * h[0];    // src/NeRF.py:151,157
     metrics[1] = (float)(-10.0 * log10((double)h[0]));                  // get_psnr, UtilsNeuralRadianceField.py:123-132
     metrics[2] = fine ? (float)(-10.0 * log10((double)h[1])) : 0.f;
     return 0;
@@ -943,6 +947,7 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     }
     t->cfg = *cfg;
     t->training = true;
+    t->loss_w[0] = t->loss_w[1] = 1.f;
     t->mixed = cfg->mixed_float16 != 0;
     {
         OptState h{};
@@ -1038,6 +1043,16 @@ int nerf_train_set_learning_rate(nerf_ctx* c, float lr) {
     if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
     if (!(lr > 0.f)) return fail("learning_rate must be positive");
     c->train->cfg.learning_rate = lr;
+    return 0;
+}
+
+int nerf_train_set_loss_weights(nerf_ctx* c, float coarse_mse_weight, float fine_mse_weight) {
+    if (!c || !c->train || !c->train->training) return fail("nerf_train_begin has not been called");
+    if (!(coarse_mse_weight >= 0.f) || !(fine_mse_weight >= 0.f) || !(coarse_mse_weight <= 3.0e38f) ||
+        !(fine_mse_weight <= 3.0e38f))
+        return fail("loss weights must be finite and non-negative (got %g, %g)", coarse_mse_weight, fine_mse_weight);
+    c->train->loss_w[0] = coarse_mse_weight;
+    c->train->loss_w[1] = fine_mse_weight;
     return 0;
 }
 

@@ -117,12 +117,13 @@ struct OptState {
     long long iterations;        // Adam updates applied
     long long skipped;           // steps dropped because their gradients were not finite
 };
-void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float* d_rgb, float* mse_out,
+void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float weight, float* d_rgb, float* mse_out,
                 hipStream_t s);         // d_rgb carries st->scale (LossScaleOptimizer.get_scaled_loss)
 void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, OptState* st, hipStream_t s,
                           bool check_only = false,     // check_only: finiteness test alone (after a gradient all-reduce)
                           const float* add_a = nullptr, const float* add_b = nullptr);   // blobs added after the test
-void launch_metrics_accum(const float* scal, bool fine, double* acc /* [4]: loss, psnr_c, psnr_f, steps */, hipStream_t s);
+void launch_metrics_accum(const float* scal, bool fine, float w0, float w1, double* acc /* [4]: loss, psnr_c, psnr_f, steps */,
+                          hipStream_t s);
 void launch_scale_by_loss_scale(const float* in, long long n, const OptState* st, float* out, hipStream_t s);
 void launch_opt_begin(OptState* st, hipStream_t s);                            // before a gradient computation: finite = 1
 void launch_opt_verdict(OptState* st, hipStream_t s);                          // after the gradients: scale bookkeeping, apply_ok

@@ -1777,10 +1777,12 @@ void launch_train_encode(const float* o, const float* d, const float* z, long lo
 // One workgroup, fixed reduction order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ tgt,
-                                                   long long n3, const OptState* __restrict__ st,
+                                                   long long n3, const OptState* __restrict__ st, float weight,
                                                    float* __restrict__ d_rgb, float* __restrict__ out) {
     __shared__ float red[1024];
-    const float scale = st->scale * 2.0f / (float)n3;      // st->scale: LossScaleOptimizer.get_scaled_loss (1 = none)
+    // st->scale: LossScaleOptimizer.get_scaled_loss (1 = none); weight: this term's factor in the ray loss (1 in
+    // NeRF.train_step; nerf_train_set_loss_weights) -- out[0] stays the plain MSE (the PSNR metrics read it)
+    const float scale = st->scale * 2.0f / (float)n3 * weight;
     float s = 0.f;
     for (long long i = threadIdx.x; i < n3; i += 1024) {
         const float e = rgb[i] - tgt[i];
@@ -1796,9 +1798,9 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
     if (threadIdx.x == 0) out[0] = red[0] / (float)n3;
 }
 
-void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float* d_rgb, float* mse_out,
-                hipStream_t s) {
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, rgb, target, N * 3, st, d_rgb, mse_out);
+void launch_mse(const float* rgb, const float* target, long long N, const OptState* st, float weight, float* d_rgb,
+                float* mse_out, hipStream_t s) {
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, rgb, target, N * 3, st, weight, d_rgb, mse_out);
 }
 
 // LossScaleOptimizer.get_unscaled_gradients + its finiteness test in one sweep: g *= inv_scale; *all_finite = 0 as soon
@@ -1833,16 +1835,17 @@ void launch_unscale_check(float* ga, float* gb, size_t n, OptState* st, hipStrea
 // Keras' History keeps the per-epoch MEANS of train_step's metrics (src/NeRF.py:169-177, src/ExecutionRun.py:192): the sums
 // are kept on the device (one thread per step), so a training loop reads them once per epoch instead of once per step.
 // scal[0] / scal[1] = this step's coarse / fine MSE (mse_kernel); the values added are exactly what read_metrics hands out.
-__global__ void metrics_accum_kernel(const float* __restrict__ scal, int fine, double* __restrict__ acc) {
+__global__ void metrics_accum_kernel(const float* __restrict__ scal, int fine, float w0, float w1,
+                                     double* __restrict__ acc) {
     const float h0 = scal[0], h1 = fine ? scal[1] : 0.f;
-    acc[0] += (double)(fine ? h0 + h1 : h0);
+    acc[0] += (double)(fine ? w0 * h0 + w1 * h1 : w0 * h0);      // as read_metrics (train_api.hip) forms the loss
     acc[1] += (double)(float)(-10.0 * log10((double)h0));
     acc[2] += fine ? (double)(float)(-10.0 * log10((double)h1)) : 0.0;
     acc[3] += 1.0;
 }
 
-void launch_metrics_accum(const float* scal, bool fine, double* acc, hipStream_t s) {
-    hipLaunchKernelGGL(metrics_accum_kernel, dim3(1), dim3(1), 0, s, scal, fine ? 1 : 0, acc);
+void launch_metrics_accum(const float* scal, bool fine, float w0, float w1, double* acc, hipStream_t s) {
+    hipLaunchKernelGGL(metrics_accum_kernel, dim3(1), dim3(1), 0, s, scal, fine ? 1 : 0, w0, w1, acc);
 }
 
 // LossScaleOptimizer.get_scaled_loss for a caller-supplied upstream gradient (nerf_train_render_gradients under

@@ -87,6 +87,9 @@ def fit(model, ds: RayDataset, epochs: int = 1, steps_per_epoch: Optional[int] =
     ``log_every`` steps when a progress line is asked for) -- so an epoch runs at the step rate ``bench.py`` reports."""
     ctx = model.ctx
     ctx.train_read_metric_sums()                     # start from clean sums
+    extra = getattr(model, "train_read_extra_metric_sums", None)    # DietNeRF: cosine_similarity_loss, kept by the model
+    if extra:
+        extra()
     history = []
     for _ in range(epochs):
         sums: Dict[str, float] = {}
@@ -94,6 +97,8 @@ def fit(model, ds: RayDataset, epochs: int = 1, steps_per_epoch: Optional[int] =
 
         def collect():
             part, steps = ctx.train_read_metric_sums()
+            if extra:
+                part.update(extra()[0])
             for k, v in part.items():
                 sums[k] = sums.get(k, 0.0) + v
             return part, steps

@@ -411,6 +411,11 @@ class Context:
     def train_set_learning_rate(self, learning_rate: float) -> None:
         _lib.check(self.lib.nerf_train_set_learning_rate(self.h, learning_rate))
 
+    def train_set_loss_weights(self, coarse_mse_weight: float = 1.0, fine_mse_weight: float = 1.0) -> None:
+        """Ray loss = coarse_mse_weight * MSE(coarse) + fine_mse_weight * MSE(fine).  (1, 1) = NeRF.train_step
+        (src/NeRF.py:151,157; what train_begin leaves); DietNeRF's tape differentiates (2, 1) (src/DietNeRF.py:160-170)."""
+        _lib.check(self.lib.nerf_train_set_loss_weights(self.h, float(coarse_mse_weight), float(fine_mse_weight)))
+
     def _train_inputs(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse, u_fine):
         arr = self._arrays(rays_orig, rays_dirs, real_rgb)
         n = int(rays_orig.shape[0])
@@ -429,16 +434,18 @@ class Context:
         self._auto_new_weights()
         return _metrics(m, n_f > 0 and self.loaded[1]) if want_metrics else None
 
-    def train_gradients(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0):
-        """Gradients without the update -> (metrics, grad_coarse blob, grad_fine blob | None)."""
+    def train_gradients(self, rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0,
+                        want_metrics=True, want_blobs=True):
+        """Gradients without the update -> (metrics, grad_coarse blob, grad_fine blob | None).  The gradients stay in the
+        context either way; ``want_blobs=False`` skips the copies, ``want_metrics=False`` the synchronisation (-> None)."""
         arr, n, (po, pd, pt), uc, uf = self._train_inputs(rays_orig, rays_dirs, real_rgb, n_c, n_f, u_coarse, u_fine)
         fine = n_f > 0 and self.loaded[1]
-        gc, pgc = arr.out((self.blob_size(),))
-        gf, pgf = arr.out((self.blob_size(),)) if fine else (None, None)
+        gc, pgc = arr.out((self.blob_size(),)) if want_blobs else (None, None)
+        gf, pgf = arr.out((self.blob_size(),)) if fine and want_blobs else (None, None)
         m = (C.c_float * 3)()
         _lib.check(self.lib.nerf_train_gradients(self.h, po, pd, pt, n, n_c, n_f, uc, uf, seed, pgc, pgf,
-                                                 C.cast(m, C.c_void_p), arr.mem))
-        return _metrics(m, fine), gc, gf
+                                                 C.cast(m, C.c_void_p) if want_metrics else None, arr.mem))
+        return (_metrics(m, fine) if want_metrics else None), gc, gf
 
     def train_render_gradients(self, rays_orig, rays_dirs, d_rgb, n_c, n_f, u_coarse=None, u_fine=None, seed=0,
                                ray_base=0, accumulate=False):

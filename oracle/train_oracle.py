@@ -301,3 +301,80 @@ def adam_update(w: np.ndarray, m: np.ndarray, v: np.ndarray, g: np.ndarray, t: i
     m = beta1 * m + (1.0 - beta1) * g
     v = beta2 * v + (1.0 - beta2) * g * g
     return w - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DietNeRF.train_step (src/DietNeRF.py:120-222) as ONE autograd graph: ray loss + consistency loss, summed before the
+# single gradient computation (:139-140).  The embedding network is an argument (the reference's is a TF-Hub remote
+# fetch, :14,75-78): any torch module of `dtype`.  No reference fixture holds these gradients: parity unpinned beyond
+# autograd of the restated forward.
+# ---------------------------------------------------------------------------------------------------------------------
+EMBEDDER_INPUT_SIZE = 224                                              # src/DietNeRF.py:15
+
+
+def embedder_preprocess(images: torch.Tensor) -> torch.Tensor:
+    """src/DietNeRF.py:275-281: tf.image.resize(images, (224, 224)) * 2 - 1 -- TF2's resize defaults: bilinear,
+    half-pixel centres, antialias=False (torch: align_corners=False)."""
+    x = torch.nn.functional.interpolate(images.permute(0, 3, 1, 2), size=(EMBEDDER_INPUT_SIZE, EMBEDDER_INPUT_SIZE),
+                                        mode="bilinear", align_corners=False, antialias=False)
+    return x.permute(0, 2, 3, 1) * 2 - 1
+
+
+def keras_cosine_similarity(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """keras.losses.cosine_similarity (Keras 2.7): -sum(l2_normalize(a) * l2_normalize(b), axis=-1) with
+    l2_normalize(x) = x * rsqrt(max(sum(x^2), 1e-12))."""
+    l2n = lambda x: x * torch.rsqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))       # noqa: E731
+    return -(l2n(a) * l2n(b)).sum(-1)
+
+
+def consistency_loss(embedding_source: torch.Tensor, embedding_target: torch.Tensor) -> torch.Tensor:
+    """src/DietNeRF.py:262-272: squeeze((1 + cosine_similarity(source[None], target[None])) / 2)."""
+    return ((1 + keras_cosine_similarity(embedding_source[None], embedding_target[None])) / 2).squeeze()
+
+
+def dietnerf_gradients(blob_c, blob_f, rays_o, rays_d, target, near, far, u_c, u_f, img_o, img_d, img_u_c, img_u_f,
+                       img_side, embed, target_embedding, cs_weight=0.1, dtype=torch.float64, **kw):
+    """One DietNeRF.train_step on a consistency-loss step, up to the gradients.
+    Ray batch (rays_o, rays_d, target, u_c, u_f) as train_gradients; the source image = img_side x img_side rays
+    (img_o, img_d, row-major) rendered through NeRF.render with draws (img_u_c, img_u_f) and Sc = Sf = their widths.
+    -> dict(loss, loss_for_rays, cosine_similarity_loss, psnr_coarse, psnr_fine, grad_coarse, grad_fine, image)."""
+    shape_kw = {k: kw[k] for k in ("n_pos_enc_xyz", "n_pos_enc_dir", "n_angles") if k in kw}
+    n_xyz, n_dir, n_angles = kw.get("n_pos_enc_xyz", 5), kw.get("n_pos_enc_dir", 4), kw.get("n_angles", 2)
+    alpha, ls = kw.get("alpha", 0.05), kw.get("fp16_loss_scale")
+    pc = blob_to_params(blob_c, dtype, **shape_kw)
+    pf = blob_to_params(blob_f, dtype, **shape_kw) if blob_f is not None else None
+    T = lambda a: torch.tensor(np.asarray(a), dtype=dtype)                                         # noqa: E731
+    # _rgb_render_loss, src/DietNeRF.py:159-172 -- statement by statement (tensors are values: `loss` keeps MSE_c)
+    o, d, tgt = T(rays_o), T(rays_d), T(target)
+    z = T(O.get_z_values(near, far, np.asarray(u_c, np.float32)))
+    coarse_render, weights_coarse = _render_rays(pc, o, d, z, n_xyz, n_dir, n_angles, alpha, ls)   # :163
+    mse_c = ((coarse_render - tgt) ** 2).mean()
+    loss_for_rays = mse_c                                                                          # :164
+    loss = loss_for_rays                                                                           # :165
+    mse_f = None
+    if pf is not None:
+        z_from_dist = _sample_pdf(weights_coarse, z, T(u_f))                                       # :168
+        fine_render, _ = _render_rays(pf, o, d, z_from_dist, n_xyz, n_dir, n_angles, alpha, ls)    # :169
+        mse_f = ((fine_render - tgt) ** 2).mean()
+        loss_for_rays = loss_for_rays + mse_f                                                      # :170
+        loss = loss + loss_for_rays                                                                # :171  (2 MSE_c + MSE_f)
+    # calc_consistency_loss, src/DietNeRF.py:204-222: render_image -> render per batch (src/NeRF.py:109-134)
+    io, idr = T(img_o), T(img_d)
+    zi = T(O.get_z_values(near, far, np.asarray(img_u_c, np.float32)))
+    rgb, w_c = _render_rays(pc, io, idr, zi, n_xyz, n_dir, n_angles, alpha, ls)
+    if pf is not None:
+        z_f = _sample_pdf(w_c, zi, T(img_u_f))
+        z_m = torch.sort(torch.cat([z_f, zi], -1), -1).values
+        rgb, _ = _render_rays(pf, io, idr, z_m, n_xyz, n_dir, n_angles, alpha, ls)
+    rendered_image = rgb.reshape(img_side, img_side, 3)
+    source_image_embedding = embed(embedder_preprocess(rendered_image[None]))[0]                   # :219
+    cs = cs_weight * consistency_loss(source_image_embedding, T(target_embedding))                 # :220-221
+    loss = loss + cs                                                                               # :139-140
+    loss.backward()
+    g = lambda ps: np.concatenate([(t.grad if t.grad is not None else torch.zeros_like(t)).numpy().ravel()   # noqa: E731
+                                   for t in ps])
+    psnr = lambda m: float(-10.0 * math.log10(float(m.detach())))                                  # noqa: E731
+    return dict(loss=float(loss.detach()), loss_for_rays=float(loss_for_rays.detach()),
+                cosine_similarity_loss=float(cs.detach()), psnr_coarse=psnr(mse_c),
+                psnr_fine=psnr(mse_f) if mse_f is not None else None, grad_coarse=g(pc),
+                grad_fine=g(pf) if pf is not None else None, image=rendered_image.detach().numpy())
