@@ -529,6 +529,48 @@ def main():
                                             mixed_float16_policy=dict(rg16, note="the reference's production policy: d_rgb "
                                                                       "loss-scaled on the device, single-pass fp16 chain, "
                                                                       "unscaled gradients, one verdict per image"))
+            # ... and the whole DietNeRF.train_step cycle through the model class (nerf_and_dietnerf_amd/dietnerf.py): 2048-ray
+            # batches x (64 + 128) (256px_alexander_71pics_sphere_dietnerf.yaml), every 13th step with the 150x150 x (55 + 55)
+            # consistency render + backward.  The embedding network is the caller's (the reference's ViT-B/32 is a TF-Hub
+            # fetch): a small conv stand-in here, so the cycle time is the LIBRARY's share of a DietNeRF cycle
+            def dietnerf_cycle(mixed):
+                conv = torch.nn.Conv2d(3, 16, 16, 16).cuda()
+                lin = torch.nn.Linear(16 * 14 * 14, 64).cuda()
+                for prm in list(conv.parameters()) + list(lin.parameters()):
+                    prm.requires_grad_(False)
+                emb = lambda x: lin(torch.tanh(conv(x.permute(0, 3, 1, 2))).flatten(1))       # noqa: E731
+                gen4 = torch.Generator(device="cuda").manual_seed(4)
+                imgs = torch.rand((4, 64, 64, 3), device="cuda", generator=gen4)
+                poses = np.stack([sphere_matrix(1.0, -30.0 - 10 * i, 45.0 + 20 * i, 0.0) for i in range(4)])
+                dn = N.DietNeRF(dict(net_cfg, n_rays_in_batch_train=2048), {"n_render_samples_coarse": SC,
+                                "n_render_samples_fine": SF}, NEAR, FAR, imgs, poses, FOV, embedder=emb, device=dev_index)
+                dn.set_weights(blob_c, blob_f)
+                dn.compile(5e-4, mixed_float16=mixed)
+                b_o = torch.zeros((2048, 4), device="cuda"); b_o[:, 2] = 1.0; b_o[:, 3] = 1.0
+                b_d = torch.randn((2048, 4), device="cuda", generator=gen4) * 0.3; b_d[:, 2] = -1.0; b_d[:, 3] = 0.0
+                b_t = torch.rand((2048, 3), device="cuda", generator=gen4)
+                for _ in range(13):                           # one warm-up cycle (its 13th step is a consistency step)
+                    dn.train_step((b_o, b_d, b_t), want_metrics=False)
+                sync()
+                t_plain = time.perf_counter()
+                for _ in range(12):
+                    dn.train_step((b_o, b_d, b_t), want_metrics=False)
+                sync()
+                t_cs = time.perf_counter()
+                dn.train_step((b_o, b_d, b_t), want_metrics=False)       # step 26: ray loss + consistency loss
+                sync()
+                t_end = time.perf_counter()
+                ls = dn.ctx.train_loss_scale()
+                dn.ctx.train_end(); dn.ctx.close()
+                plain, cs = (t_cs - t_plain) / 12 * 1e3, (t_end - t_cs) * 1e3
+                return {"ms_per_plain_step": plain, "ms_per_consistency_step": cs, "ms_per_13_step_cycle": 12 * plain + cs,
+                        "rays_per_cycle": 13 * 2048 + 150 * 150, "steps_applied": ls[1], "steps_skipped": ls[2]}
+            cfg4["dietnerf_train_cycle"] = {
+                "float32": dietnerf_cycle(False), "mixed_float16": dietnerf_cycle(True),
+                "note": "DietNeRF.train_step through nerf_and_dietnerf_amd.DietNeRF: 2048-ray batches x (64 + 128), every 13th "
+                        "step + a 150x150 x (55 + 55) source render and its backward through NeRF.render in 2048-ray batches "
+                        "(src/DietNeRF.py:120-222); embedder = a small conv stand-in (the reference's ViT-B/32 is a remote "
+                        "fetch), so these are the library's share of the cycle"}
             # BASELINE configs[4]: 800x800, 64 coarse + 256 fine, fp16 MLP
             cfg5 = dict(side_run(model, "f16", 3, 800, 800, 64, 256, c2w, FOV),
                         workload="800x800, 64 coarse + 256 fine (fine pass 320 samples), single-pass fp16 MLP mode")

@@ -74,7 +74,7 @@ int comm_allreduce_mean(nerf_ctx* c, float* buf, size_t n);   // comm_api.hip: n
 int comm_world(const nerf_ctx* c);                            // ranks of the ctx's communicator (1 without one)
 int upload_packed_weights(nerf_ctx* c, int which, const float* blob_host);   // nerf_api.hip: pack + upload streams
 int train_on_load(nerf_ctx* c, int which);          // train_api.hip: no-op without a trainer
-int train_flush_weights(nerf_ctx* c, int which);
+int train_flush_weights(nerf_ctx* c, int which, bool to_host = false);
 // (train_flush_weights: train_api.hip, no-op unless optimizer steps changed the weights)
 
 }  // namespace nerf

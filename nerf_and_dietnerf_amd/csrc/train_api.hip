@@ -28,6 +28,7 @@ struct TLayer {
 struct TNet {
     bool present = false;
     bool render_dirty = false;     // optimizer steps not yet packed into the render path's operand streams
+    bool host_stale = false;       // ... and not yet copied to NetWeights::host_blob (the seed of the next trainer)
     float *blob = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *mats = nullptr;
     void* fstream = nullptr;       // fused forward (f16x3 stash kernel): operand stream + constants, re-packed on device
     float* fcst = nullptr;
@@ -87,6 +88,12 @@ struct TrainState {
     DevBuf z_new, d_zm, zero_rgb;   // backward through NeRF.render(): the Sf new depths, d/dz of the merged fine pass
     DevBuf macc;                    // running sums of the step metrics (4 doubles: loss, psnr_coarse, psnr_fine, steps)
     DevBuf gsave[2];                // ... under mixed_float16 with accumulate = 1: the (unscaled) gradients already there
+    // A render between optimizer steps (DietNeRF's consistency render every 13th step, the epoch plots) needs the render
+    // path's three operand streams re-packed from the trained blob: on the DEVICE, by gather tables built once from the host
+    // packers (round 4; the device -> host -> pack x 3 -> device round trip this replaces cost ~30 ms and two synchronisations
+    // per render).  rt_h / rt_h1: build_f16x3_gather (3-pass / hi-only stream), rt_ch their constants; rt_f / rt_cf: the fp32
+    // stream and constants (pack_weights_fp32 only moves values: the table is the packed INDEX blob).
+    int32_t *rt_h = nullptr, *rt_h1 = nullptr, *rt_ch = nullptr, *rt_f = nullptr, *rt_cf = nullptr;
 };
 
 }  // namespace nerf
@@ -200,7 +207,7 @@ int init_net(nerf_ctx* c, TrainState* t, int which) {
     }
     HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), nb, hipMemcpyHostToDevice, c->stream));
     n.present = true;
-    n.render_dirty = false;
+    n.render_dirty = n.host_stale = false;
     if (int r = ensure_fused(c, t, n)) return r;
     return relayout_net(c, n);
 }
@@ -883,6 +890,8 @@ void train_free(nerf_ctx* c) {
         if (n.fcst) (void)hipFree(n.fcst);
         if (n.bstream) (void)hipFree(n.bstream);
     }
+    for (int32_t* p : {t->rt_h, t->rt_h1, t->rt_ch, t->rt_f, t->rt_cf})
+        if (p) (void)hipFree(p);
     if (t->sidx) (void)hipFree(t->sidx);
     if (t->cidx) (void)hipFree(t->cidx);
     for (int32_t* bi : t->bidx) if (bi) (void)hipFree(bi);
@@ -914,19 +923,66 @@ int train_on_load(nerf_ctx* c, int which) {
     if (!n.present) return init_net(c, t, which);
     HIP_OK(hipMemcpyAsync(n.blob, c->net[which].host_blob.data(), t->nblob * sizeof(float), hipMemcpyHostToDevice,
                           c->stream));
-    n.render_dirty = false;
+    n.render_dirty = n.host_stale = false;
     return relayout_net(c, n);
 }
 
-int train_flush_weights(nerf_ctx* c, int which) {
+// gather tables of the render path's operand streams (see TrainState::rt_*)
+static int ensure_render_tables(nerf_ctx* c, TrainState* t) {
+    if (t->rt_h) return 0;
+    const int na = c->cfg.n_angles;
+    auto up = [&](const std::vector<int32_t>& v, int32_t** dst) -> int {
+        HIP_OK(hipMalloc((void**)dst, v.size() * sizeof(int32_t)));
+        HIP_OK(hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        return 0;
+    };
+    std::vector<int32_t> h(f16_stream_bytes(na, false) / 2), h1(f16_stream_bytes(na, true) / 2), ch(kConstFloats),
+        ch1(kConstFloats);
+    build_f16x3_gather(na, false, h.data(), ch.data());
+    build_f16x3_gather(na, true, h1.data(), ch1.data());
+    if (ch != ch1) return fail("internal: the two fp16 streams disagree about their constants");
+    // fp32 stream: pack a blob whose entry i holds i + 1 (exact in fp32: the blob has 5e5 entries) -- what lands in a slot
+    // is the 1-based index of the weight that belongs there, 0 where the packer pads
+    const size_t nf = (na == 0 ? kStreamBytesXyzF32 : kStreamBytes) / 4;
+    std::vector<float> idx(t->nblob), sf(nf), cf(kConstFloats);
+    for (size_t i = 0; i < t->nblob; ++i) idx[i] = (float)(i + 1);
+    pack_weights_fp32(idx.data(), na, sf.data(), cf.data());
+    std::vector<int32_t> f(nf), cfi(kConstFloats);
+    for (size_t i = 0; i < nf; ++i) f[i] = (int32_t)sf[i];
+    for (size_t i = 0; i < (size_t)kConstFloats; ++i) cfi[i] = (int32_t)cf[i];
+    if (int r = up(h1, &t->rt_h1)) return r;
+    if (int r = up(ch, &t->rt_ch)) return r;
+    if (int r = up(f, &t->rt_f)) return r;
+    if (int r = up(cfi, &t->rt_cf)) return r;
+    return up(h, &t->rt_h);                  // last: rt_h != nullptr means all five exist
+}
+
+// The render path's view of a network that is being trained.  After optimizer steps its three operand streams are
+// re-packed from the trained blob on the device (enqueued on the ctx stream: a render between steps does not synchronise);
+// to_host additionally brings NetWeights::host_blob up to date (nerf_train_end, a restarting nerf_train_begin: the next
+// trainer starts from it).
+int train_flush_weights(nerf_ctx* c, int which, bool to_host) {
     TrainState* t = c->train;
-    if (!t || !t->net[which].present || !t->net[which].render_dirty) return 0;
+    if (!t || !t->net[which].present) return 0;
+    TNet& n = t->net[which];
     NetWeights& nw = c->net[which];
-    HIP_OK(hipMemcpyAsync(nw.host_blob.data(), t->net[which].blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost,
-                          c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    t->net[which].render_dirty = false;
-    return upload_packed_weights(c, which, nw.host_blob.data());
+    if (n.render_dirty) {
+        if (int r = ensure_render_tables(c, t)) return r;
+        const int na = c->cfg.n_angles;
+        launch_repack_f16x3(n.blob, t->rt_h, nw.stream_h, t->rt_ch, nw.cst_h, f16_stream_bytes(na, false), c->stream);
+        launch_repack_f16x3(n.blob, t->rt_h1, nw.stream_h1, t->rt_ch, nw.cst_h, f16_stream_bytes(na, true), c->stream);
+        launch_gather_blob(n.blob, t->rt_f, nw.stream, (na == 0 ? kStreamBytesXyzF32 : kStreamBytes) / 4, c->stream);
+        launch_gather_blob(n.blob, t->rt_cf, nw.cst, kConstFloats, c->stream);
+        HIP_OK(hipGetLastError());
+        n.render_dirty = false;
+        n.host_stale = true;
+    }
+    if (to_host && n.host_stale) {
+        HIP_OK(hipMemcpyAsync(nw.host_blob.data(), n.blob, t->nblob * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        n.host_stale = false;
+    }
+    return 0;
 }
 
 }  // namespace nerf
@@ -938,7 +994,12 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
     if (!cfg) return fail("nerf_train_config is NULL");
     if (!(cfg->learning_rate > 0.f)) return fail("learning_rate must be positive");
     if (!c->net[0].loaded) return fail("load the coarse network's weights before nerf_train_begin");
-    if (c->train && c->train->training) train_free(c);
+    if (c->train && c->train->training) {
+        // a trainer restarted without nerf_train_end goes on from the TRAINED weights ("the weights currently loaded")
+        for (int w = 0; w < 2; ++w)
+            if (int r = train_flush_weights(c, w, true)) return r;
+        train_free(c);
+    }
     TrainState* t = c->train;           // an inference-only state (xyz-only network) is promoted in place
     if (!t) {
         t = new TrainState();
@@ -1007,7 +1068,7 @@ int nerf_train_begin(nerf_ctx* c, const nerf_train_config* cfg) {
 int nerf_train_end(nerf_ctx* c) {
     ENTER(c);
     for (int w = 0; w < 2; ++w)
-        if (int r = train_flush_weights(c, w)) return r;
+        if (int r = train_flush_weights(c, w, true)) return r;
     HIP_OK(hipStreamSynchronize(c->stream));
     train_free(c);
     return 0;

@@ -124,6 +124,8 @@ void launch_unscale_check(float* ga, float* gb /* nullable */, size_t n, OptStat
                           const float* add_a = nullptr, const float* add_b = nullptr);   // blobs added after the test
 void launch_metrics_accum(const float* scal, bool fine, float w0, float w1, double* acc /* [4]: loss, psnr_c, psnr_f, steps */,
                           hipStream_t s);
+// out[i] = idx[i] ? blob[idx[i] - 1] : 0 (device-side re-pack of an operand stream whose packer only moves values)
+void launch_gather_blob(const float* blob, const int32_t* idx, float* out, size_t n, hipStream_t s);
 void launch_scale_by_loss_scale(const float* in, long long n, const OptState* st, float* out, hipStream_t s);
 void launch_opt_begin(OptState* st, hipStream_t s);                            // before a gradient computation: finite = 1
 void launch_opt_verdict(OptState* st, hipStream_t s);                          // after the gradients: scale bookkeeping, apply_ok

@@ -1856,6 +1856,20 @@ __global__ void scale_by_loss_scale_kernel(const float* __restrict__ in, long lo
     if (i < n) out[i] = in[i] * st->scale;
 }
 
+__global__ void gather_blob_kernel(const float* __restrict__ blob, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                   size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t t = idx[i];
+        out[i] = t ? blob[t - 1] : 0.f;
+    }
+}
+
+void launch_gather_blob(const float* blob, const int32_t* idx, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_blob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blob, idx, out, n);
+}
+
 void launch_scale_by_loss_scale(const float* in, long long n, const OptState* st, float* out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(scale_by_loss_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, st, out);

@@ -127,6 +127,21 @@ int main(int argc, char** argv) {
             fprintf(stderr, "train: %s\n", nerf_last_error()); return 1;
         }
         printf("train_loss %.9g %.9g\n", m0[0], m1[0]);
+        /* ABI 5: the ray loss DietNeRF's tape differentiates counts the coarse MSE twice (src/DietNeRF.py:163-171): the same
+         * gradients call under (1, 1) and (2, 1) -- the loss metric moves by MSE_c = 10^(-psnr_coarse / 10), the PSNRs do not;
+         * nerf_train_begin restores (1, 1) and bad weights are refused */
+        float ma[3], mb[3], mc[3];
+        if (nerf_train_begin(ctx, &tc) ||
+            nerf_train_gradients(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 5u, NULL, NULL, ma, NERF_MEM_HOST) ||
+            nerf_train_set_loss_weights(ctx, 2.0f, 1.0f) ||
+            nerf_train_gradients(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 5u, NULL, NULL, mb, NERF_MEM_HOST) ||
+            nerf_train_end(ctx) || nerf_train_begin(ctx, &tc) ||
+            nerf_train_gradients(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 5u, NULL, NULL, mc, NERF_MEM_HOST)) {
+            fprintf(stderr, "loss weights: %s\n", nerf_last_error()); return 1;
+        }
+        const int refused = nerf_train_set_loss_weights(ctx, -1.0f, 1.0f) != 0;
+        if (nerf_train_end(ctx)) { fprintf(stderr, "loss weights: %s\n", nerf_last_error()); return 1; }
+        printf("loss_weights %.9g %.9g %.9g psnr %.9g %.9g refused %d\n", ma[0], mb[0], mc[0], ma[1], mb[1], refused);
         /* the same under the reference's production policy: mixed_float16 with dynamic loss scaling; an infinite target is a
          * SKIPPED step that halves the scale (ABI 2/3) */
         nerf_train_config tm = {5e-4f, 0.9f, 0.999f, 1e-7f, 1, 1, 1024.0f, 0};

@@ -643,6 +643,12 @@ def test_c_abi_client(tmp_path, oracle):
     assert re.search(r"sharded_equal 1", res.stdout), res.stdout
     tl = re.search(r"train_loss (\S+) (\S+)", res.stdout)
     assert tl and 0 < float(tl.group(2)) < float(tl.group(1)), res.stdout
+    # ABI 5: loss weights (2, 1) = DietNeRF's ray loss: the loss metric grows by MSE_c, the PSNR metrics stay, a new
+    # nerf_train_begin is back at (1, 1), negative weights are refused
+    lw = re.search(r"loss_weights (\S+) (\S+) (\S+) psnr (\S+) (\S+) refused (\d)", res.stdout)
+    assert lw, res.stdout
+    la, lb, lc, pa, pb = (float(lw.group(i)) for i in range(1, 6))
+    assert abs((lb - la) - 10 ** (-pa / 10)) <= 2e-6 * lb and pa == pb and lc == la and lw.group(6) == "1", res.stdout
     # ... and through the mixed_float16 policy: one applied step, then an infinite target = a skipped step and half the scale
     mx = re.search(r"mixed (\S+) (\S+) (\S+) (\S+)", res.stdout)
     assert mx and np.isfinite(float(mx.group(1))) and (float(mx.group(2)), int(mx.group(3)), int(mx.group(4))) == (512.0, 1, 1), res.stdout

@@ -206,6 +206,69 @@ def test_train_steps_reduce_loss_and_render_sees_new_weights(oracle, golden_ckpt
     ctx.close()
 
 
+@pytest.mark.parametrize("n_angles", [2, 1, 0])
+def test_render_between_steps_uses_device_repacked_streams(oracle, golden_ckpt, n_angles):
+    """A render between optimizer steps (DietNeRF's consistency render, the epoch plots) re-packs the render path's three
+    operand streams from the trained blob ON THE DEVICE (gather tables built from the host packers; no host round trip).  In
+    every arithmetic mode and for every network variant the result must be bit-equal to a fresh context that loads
+    nerf_get_weights() through the host packers; more steps dirty the streams again; nerf_train_end leaves the host copy
+    current (a second trainer starts from the trained weights) and so does a nerf_train_begin that restarts a running
+    trainer."""
+    import nerf_and_dietnerf_amd as N
+    p = _problem(oracle, golden_ckpt, n=64, sc=12, sf=20, seed=6)
+    if n_angles == 2:
+        bc, bf = p["bc"], p["bf"]
+    else:
+        bc, bf = N.glorot_blob(3, n_angles=n_angles), N.glorot_blob(4, n_angles=n_angles)
+    kw = dict(near=p["near"], far=p["far"], n_angles=n_angles)
+    draws = (p["sc"], p["sf"], p["u_c"], p["u_f"])
+
+    def render_all(c):
+        out = {}
+        for prec in ("fp32", "f16x3", "f16"):
+            c.set_precision(prec)
+            out[prec] = c.render(p["o"], p["d"], *draws)
+        return out
+
+    def fresh(wc, wf):
+        c = N.Context(precision="fp32", **kw)
+        c.load_weights(0, wc); c.load_weights(1, wf)
+        out = render_all(c)
+        c.close()
+        return out
+
+    ctx = N.Context(precision="fp32", **kw)
+    ctx.load_weights(0, bc); ctx.load_weights(1, bf)
+    ctx.train_begin(1e-3)
+    for rnd in range(2):                                   # render, step on, render again: the streams follow the blob
+        for i in range(3):
+            ctx.train_step(p["o"], p["d"], p["tgt"], *draws, want_metrics=False)
+        got = render_all(ctx)
+        wc, wf = ctx.get_weights(0), ctx.get_weights(1)
+        assert np.abs(wc - bc).max() > 1e-4
+        want = fresh(wc, wf)
+        for prec in want:
+            for a, b in zip(got[prec], want[prec]):
+                np.testing.assert_array_equal(a, b, err_msg=f"{prec}, round {rnd}")
+    # a restart without nerf_train_end goes on from the trained weights ...
+    ctx.train_step(p["o"], p["d"], p["tgt"], *draws, want_metrics=False)
+    w_before = ctx.get_weights(1)
+    ctx.train_begin(1e-3)
+    np.testing.assert_array_equal(ctx.get_weights(1), w_before)
+    ctx.train_step(p["o"], p["d"], p["tgt"], *draws, want_metrics=False)
+    # ... and nerf_train_end leaves render streams AND the host copy at the final weights
+    wc, wf = ctx.get_weights(0), ctx.get_weights(1)
+    ctx.train_end()
+    np.testing.assert_array_equal(ctx.get_weights(0), wc)
+    np.testing.assert_array_equal(ctx.get_weights(1), wf)
+    got, want = render_all(ctx), fresh(wc, wf)
+    for prec in want:
+        np.testing.assert_array_equal(got[prec][0], want[prec][0])
+    ctx.train_begin(1e-3)
+    np.testing.assert_array_equal(ctx.get_weights(1), wf)
+    ctx.close()
+
+
 def test_nerf_mirror_train_step_and_full_batch_timing(oracle, golden_ckpt, capsys):
     """NeRF.compile + NeRF.train_step (the reference's names) at the reference's batch: 4096 rays, 64 + 128."""
     import time
