@@ -286,3 +286,59 @@ def test_dietnerf_data_parallel_step_equals_single_rank(oracle, golden_ckpt):
         assert _relerr(gc, gc_full) <= 1e-5 and _relerr(gf, gf_full) <= 1e-5, rank
         assert np.abs(w - w_full).max() <= 1e-6
     np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+def test_get_nerf_from_the_reference_configs(oracle, golden_ckpt, tmp_path, capsys):
+    """ExecutionRun.get_nerf / _init_dietnerf (src/ExecutionRun.py:216-262) from the reference's own YAML files (data fixtures
+    under tests/golden/configs/) on its shipped 50-pixel dataset: config[0] as the shipped run kept it -> a compiled NeRF under
+    the mixed_float16 policy with the epoch-95 checkpoint loaded from <save_location>/saved_weights (written here with
+    save_nerf_checkpoint), whose render of the test view reaches the recorded PSNR class; the few-views DietNeRF config ->
+    a compiled DietNeRF with the consistency loss limited to 95 % of the steps, spherical pose sampling around a supplied point
+    of interest with the test view's rotation, Glorot weights when nothing is saved; both train."""
+    import os
+    import torch
+    import nerf_and_dietnerf_amd as N
+    from nerf_and_dietnerf_amd import config as C
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = C.load_config(os.path.join(here, "golden", "configs", "50px_alexander_71pics_sphere_nerf_save_dir_4.yaml"))
+    cfg[C.DATASET_LOCATION] = "alexander50"
+    images, poses, fov, near, far, _, _ = C.get_data(cfg, os.path.join(here, "golden"))
+    os.makedirs(tmp_path / "saved_weights")
+    N.save_nerf_checkpoint(str(N.NeRF.get_nerf_model_path(tmp_path, 95)), golden_ckpt["blob_coarse"], golden_ckpt["blob_fine"])
+    model = C.get_nerf(cfg, near, far, save_location=tmp_path)
+    assert type(model) is N.NeRF and model._mixed and model.batch_size_train == 4096
+    np.testing.assert_array_equal(model.ctx.get_weights(1), golden_ckpt["blob_fine"])
+    idx_test, tr_img, tr_pose = C.get_train_data(cfg, images, poses)
+    rgb = model.render_image(poses[idx_test], fov, 50, 50, seed=3)[0]
+    psnr = -10 * np.log10(np.mean((np.clip(rgb, 0, 1) - images[idx_test]) ** 2))
+    ds = N.prepare_ds(cfg[C.NEURAL_NET][C.N_RAYS_IN_BATCH_TRAIN], tr_pose[:4], tr_img[:4], fov, model.ctx)
+    hist = N.fit(model, ds, epochs=1)
+    with capsys.disabled():
+        print(f"\n[get_nerf, config[0] of the shipped run] test view {idx_test}: {psnr:.2f} dB (recorded by the reference: 27.83); "
+              f"one epoch on 4 views: " + ", ".join(f"{k} {v:.4f}" for k, v in hist[0].items()))
+    assert psnr > 26.5 and np.isfinite(hist[0]["loss"]) and model.ctx.train_loss_scale()[2] == 0
+    model.ctx.close()
+    # --- type_of_model: DietNeRF, pics_indices_to_use_in_dataset: five views ---
+    dcfg = C.load_config(os.path.join(here, "golden", "configs", "256px_alexander_71pics_sphere_dietnerf_use5pics.yaml"))
+    assert dcfg[C.NEURAL_NET][C.TYPE_OF_MODEL] == "DietNeRF"
+    with pytest.raises(ValueError, match="needs images"):
+        C.get_nerf(dcfg, near, far)
+    poi = np.array([0.0, 0.0, 0.0])
+    dn = C.get_nerf(dcfg, near, far, images=images, camera_poses=poses, field_of_view=fov, save_location=tmp_path / "none",
+                    embedder=_embedder(torch.float32, "cuda"), estimated_intersection=poi, seed=2)
+    keep = [i for i in dcfg[C.PICS_INDICES_TO_USE_IN_DATASET] if i != dcfg[C.TRAINING][C.TEST_IMG_IDX]]
+    n_batches = (len(keep) * 50 * 50) // 2048
+    assert type(dn) is N.DietNeRF and dn.target_images_embedding.shape[0] == len(keep) and dn.batch_size_train == 2048
+    assert dn.max_steps_of_consistency_loss == int(n_batches * dcfg[C.TRAINING][C.N_EPOCHS] * 0.95)
+    assert dn.is_spherical_dataset
+    np.testing.assert_allclose(dn.rot_mat_to_in_front_of_point_of_interest[:3, :3],
+                               poses[dcfg[C.TRAINING][C.TEST_IMG_IDX]][:3, :3])
+    np.testing.assert_array_equal(dn.ctx.get_weights(0), N.glorot_blob(0))        # nothing saved: fresh Glorot networks
+    _, d_img, d_pose = C.get_train_data(dcfg, images, poses)
+    ds = N.prepare_ds(dn.batch_size_train, d_pose, d_img, fov, dn.ctx)
+    hist = N.fit(dn, ds, epochs=3)
+    assert 13 <= dn.counter == 3 * len(ds) < 26 and dn.last_consistency is not None
+    e13 = 12 // len(ds)                                             # the epoch that holds step 13, the one consistency step
+    assert [h["cosine_similarity_loss"] > 0 for h in hist] == [e == e13 for e in range(3)]
+    assert hist[2]["loss"] < hist[0]["loss"] and dn.ctx.train_loss_scale()[2] == 0
+    dn.ctx.close()
