@@ -166,12 +166,18 @@ class DietNeRF(NeRF):
         rand_index = int(self.rng.integers(0, len(self.target_images_embedding)))
         target_image_embedding = self.target_images_embedding[rand_index]
         pose = self.sample_random_source_pose()
-        self.last_consistency = {"target_index": rand_index, "pose": pose, "seed": int(seed)}    # (for plots and tests)
         world = dist_world(group)
         rank = 0
         if world > 1:
+            # every rank must render the SAME image against the SAME target: rank 0's draws count (ranks whose generators
+            # were seeded alike drew the same values anyway; this removes the requirement)
             import torch.distributed as dist
             rank = dist.get_rank(group)
+            box = [(rand_index, pose, int(seed))]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            rand_index, pose, seed = box[0]
+            target_image_embedding = self.target_images_embedding[rand_index]
+        self.last_consistency = {"target_index": rand_index, "pose": pose, "seed": int(seed)}    # (for plots and tests)
         begin, count = ray_slab(s * s, rank, world)
         # the image the embedder sees is the forward of the tape that is differentiated below: under mixed_float16 that
         # tape runs the single-pass fp16 network, so the image is rendered in that arithmetic too (the reference has ONE

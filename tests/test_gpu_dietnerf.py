@@ -240,6 +240,8 @@ def _dp_rank(rank, world, port, q, golden, seed):
         from oracle import nerf_oracle as O
         model, data, p = _setup(O, golden, 1.0, mixed=False, seed=seed)
         model.counter = 12
+        if rank:                       # another generator state than rank 0's: the source pose and target are rank 0's anyway
+            model.rng = np.random.default_rng(1234)
         n = p["n"] // world
         shard = tuple(t[rank * n:(rank + 1) * n].contiguous() for t in data)
         # explicit draws: the device generator numbers rays within the batch a rank passes, so shards would draw differently
