@@ -198,7 +198,11 @@ typedef struct nerf_train_config {
     int32_t dynamic_growth_steps;  /* 0 -> 2000 */
 } nerf_train_config;
 
-/* Starts a trainer on the weights currently loaded (coarse required, fine optional); zero Adam moments. */
+/* Starts a trainer on the weights currently loaded (coarse required, fine optional); zero Adam moments.  Called while a
+ * trainer is running it restarts the optimizer on the TRAINED weights (and resets the loss weights to 1, 1).
+ * Rendering between optimizer steps is allowed at any time (DietNeRF's consistency render, the epoch plots,
+ * src/ExecutionRun.py:193-201): the render path's operand streams are re-packed from the trained weights on the device,
+ * enqueued on the ctx stream, without a host round trip. */
 int nerf_train_begin(nerf_ctx* ctx, const nerf_train_config* cfg);
 /* Packs the trained weights for the render path and frees optimizer state and activation buffers. */
 int nerf_train_end(nerf_ctx* ctx);
