@@ -185,8 +185,10 @@ class DietNeRF(NeRF):
         keep = ctx.precision
         if getattr(self, "_mixed", False) and keep != "f16":
             ctx.set_precision("f16")
-        slab = ctx.render_image(pose, self.fov, s, s, self.batch_size_train, n_c, n_f, seed=seed, ray_begin=begin,
-                                ray_count=count, device_out=True, rgb_only=True)[0].reshape(-1, 3)
+        # (the reference renders in batch_size_train batches to bound TensorFlow's activation memory, src/DietNeRF.py:215-218;
+        # nothing per layer is materialised here and results do not depend on the batch: the library's own batch)
+        slab = ctx.render_image(pose, self.fov, s, s, 0, n_c, n_f, seed=seed, ray_begin=begin, ray_count=count,
+                                device_out=True, rgb_only=True)[0].reshape(-1, 3)
         if ctx.precision != keep:
             ctx.set_precision(keep)
         flat = gather_slabs(slab, s * s, group) if world > 1 else slab

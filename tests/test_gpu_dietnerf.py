@@ -344,3 +344,37 @@ def test_get_nerf_from_the_reference_configs(oracle, golden_ckpt, tmp_path, caps
     assert [h["cosine_similarity_loss"] > 0 for h in hist] == [e == e13 for e in range(3)]
     assert hist[2]["loss"] < hist[0]["loss"] and dn.ctx.train_loss_scale()[2] == 0
     dn.ctx.close()
+
+
+def test_dietnerf_without_a_fine_network(oracle, golden_ckpt, capsys):
+    """n_render_samples_fine = 0 (src/NeRF.py:36-39; src/DietNeRF.py:166: `if self.model_fine`): the ray loss is MSE_c alone --
+    no doubled term -- and the consistency loss reaches the coarse network directly, through its own render."""
+    import torch
+    import nerf_and_dietnerf_amd as N
+    from oracle import train_oracle as T
+    model, data, p = _setup(oracle, golden_ckpt, 1.0, mixed=False, sf=0)
+    assert model.model_fine is None
+    model.counter = 12
+    metrics, used, (gc, gf) = model.compute_gradients(data, seed=31)
+    assert used and gf is None and "psnr_fine" not in metrics
+    lc = model.last_consistency
+    side, s = p["side"], p["samples"]
+    ray, pix = np.arange(p["n"], dtype=np.uint64), np.arange(side * side, dtype=np.uint64)
+    img_d = oracle.get_rays_directions(side, side, p["fov"], lc["pose"]).reshape(-1, 4)
+    img_o = np.broadcast_to(lc["pose"][:, 3], img_d.shape).astype(np.float32)
+    emb64 = _embedder(torch.float64, "cpu")
+    targets = emb64(T.embedder_preprocess(torch.tensor(p["images"], dtype=torch.float64)))
+    r = T.dietnerf_gradients(golden_ckpt["blob_coarse"], None, p["o"], p["d"], p["tgt"], p["near"], p["far"],
+                             oracle.philox_uniform(31, ray, p["sc"], 0), None, img_o, img_d,
+                             oracle.philox_uniform(lc["seed"], pix, s, 0), None, side, emb64,
+                             targets[lc["target_index"]].numpy(), alpha=1.0)
+    gc = gc.cpu().numpy()
+    ec = _relerr(gc, r["grad_coarse"])
+    with capsys.disabled():
+        print(f"\n[DietNeRF, coarse network only] gradient vs float64 autograd {ec:.2e} of max|g|; loss {metrics['loss']:.5f} "
+              f"(oracle {r['loss'] + r['cosine_similarity_loss']:.5f})")
+    assert ec <= 5e-4 and _cos(gc, r["grad_coarse"]) > 0.9999999
+    assert abs(metrics["loss_for_rays"] - r["loss_for_rays"]) <= 5e-6 * r["loss_for_rays"]
+    assert abs(metrics["loss"] - (r["loss"] + r["cosine_similarity_loss"])) <= 5e-6 * r["loss"]
+    model.ctx.train_apply()
+    model.ctx.close()
