@@ -263,6 +263,25 @@ int nerf_train_render_gradients(nerf_ctx* ctx, const float* rays_orig, const flo
                                 int64_t N, int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine,
                                 uint64_t seed, int64_t ray_base, int32_t accumulate, float* rgb_out,
                                 float* grad_coarse, float* grad_fine, int mem);
+/* ABI 5: the same graph in two calls, the activations kept in between -- for callers whose d_rgb depends on the WHOLE image
+ * (DietNeRF: the embedding network sees all 150 x 150 pixels before any gradient exists, src/DietNeRF.py:215-221).  The reference
+ * renders the image once, under the tape; with nerf_render_image + nerf_train_render_gradients the forward runs twice.  Here:
+ *   nerf_train_render_forward(slot = b, batch b of the rays, ...) for every batch -- rgb_out is that batch's part of the image,
+ *     the forward of the tape itself (under mixed_float16: the single-pass fp16 network), its activations stay in slot b
+ *     (about 1.7 MB per ray at 55 + 110 rows under the float32 policy, half under mixed_float16: a 150 x 150 image is 38 / 19
+ *     GB of the device's 288 GB; slots are grow-only buffers, nerf_train_render_release or nerf_train_end frees them);
+ *   ... the caller turns the image into d_rgb ...
+ *   nerf_train_render_backward(slot = b, d_rgb of batch b, accumulate, ...) for every batch: exactly the backward half of
+ *     nerf_train_render_gradients -- bit-identical gradients, same loss-scale handling -- on the kept activations.
+ * A slot holds one forward pass: a backward pass consumes it, an optimizer step (nerf_train_apply / nerf_train_step) invalidates
+ * every slot (the activations belong to the weights that made them), a new forward into the slot overwrites it.  The slot keeps
+ * its own copies of rays and draws.  slot: 0..4095. */
+int nerf_train_render_forward(nerf_ctx* ctx, int32_t slot, const float* rays_orig, const float* rays_dirs, int64_t N,
+                              int32_t Sc, int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed,
+                              int64_t ray_base, float* rgb_out, int mem);
+int nerf_train_render_backward(nerf_ctx* ctx, int32_t slot, const float* d_rgb, int32_t accumulate, float* grad_coarse,
+                               float* grad_fine, int mem);
+int nerf_train_render_release(nerf_ctx* ctx);
 /* ABI 3: the gradient blob of a network as the ctx holds it now -- after nerf_train_gradients /
  * nerf_train_render_gradients the gradients just computed, after a data-parallel nerf_train_step the all-reduced mean
  * the Adam update used (what the reference's tape.gradient returns, src/NeRF.py:159-165). */

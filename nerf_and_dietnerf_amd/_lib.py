@@ -81,6 +81,9 @@ SYMBOLS = [
     ("nerf_train_apply", C.c_int, [_P, _P, _P, C.c_int]),
     ("nerf_train_render_gradients", C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, _I32, _P, _P, _P,
                                               C.c_int]),
+    ("nerf_train_render_forward", C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _P, _P, _U64, _I64, _P, C.c_int]),
+    ("nerf_train_render_backward", C.c_int, [_P, _I32, _P, _I32, _P, _P, C.c_int]),
+    ("nerf_train_render_release", C.c_int, [_P]),
     ("nerf_train_get_gradients", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_get_weights", C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int]),
     ("nerf_ctx_enable_timing", C.c_int, [_P, C.c_int]),

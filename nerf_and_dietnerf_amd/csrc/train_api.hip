@@ -46,6 +46,22 @@ struct TPass {                      // activations of one pass, kept from forwar
     DevBuf rs;                         // pair16 gradient buffers (float32 policy): 10 x Mp row factors (MlpBwdArgs::rs_ptr)
 };
 
+// nerf_train_render_forward / _backward (ABI 5): the activations of one ray batch of NeRF.render(), kept from a forward to
+// its backward while other batches run -- a whole source image of DietNeRF's consistency loss stays resident (150 x 150 rays x
+// (55 + 110) rows: 38 GB under the float32 policy, 19 GB under mixed_float16 of this device's 288 GB) instead of being
+// rendered once for the embedding network and a second time under the tape.  A slot owns the STASH side of two passes, its
+// own copies of the rays and draws, and the new depths; the gradient side of a TPass (D, dxa, dxb, rs) is lent by
+// TrainState::pass while the slot runs.
+struct RenderSlot {
+    TPass pass[2];
+    DevBuf o, d, u_c, u_f, z_new;
+    long long N = 0, ray_base = 0;
+    int Sc = 0, Sf = 0;
+    unsigned long long seed = 0;
+    bool has_uc = false, has_uf = false, valid = false;
+};
+constexpr int kMaxRenderSlots = 4096;
+
 struct TrainState {
     nerf_train_config cfg;
     bool training = false;          // set by nerf_train_begin
@@ -94,6 +110,7 @@ struct TrainState {
     // per render).  rt_h / rt_h1: build_f16x3_gather (3-pass / hi-only stream), rt_ch their constants; rt_f / rt_cf: the fp32
     // stream and constants (pack_weights_fp32 only moves values: the table is the packed INDEX blob).
     int32_t *rt_h = nullptr, *rt_h1 = nullptr, *rt_ch = nullptr, *rt_f = nullptr, *rt_cf = nullptr;
+    std::vector<RenderSlot> slots;  // nerf_train_render_forward / _backward
 };
 
 }  // namespace nerf
@@ -843,6 +860,191 @@ int render_gradients_impl(nerf_ctx* c, const float* rays_o, const float* rays_d,
     return 0;
 }
 
+// ---- the same graph in two calls, with the activations kept in between (RenderSlot) -------------------------------------
+static void swap_grad_members(TPass& a, TPass& b) {
+    for (int l = 0; l < 10; ++l) std::swap(a.D[l], b.D[l]);
+    std::swap(a.dxa, b.dxa);
+    std::swap(a.dxb, b.dxb);
+    std::swap(a.rs, b.rs);
+}
+// the slot's stash becomes TrainState::pass (which forward_pass / backward_pass work on), keeping the working gradient buffers
+static void slot_swap_in(TrainState* t, RenderSlot& s) {
+    for (int w = 0; w < 2; ++w) {
+        std::swap(t->pass[w], s.pass[w]);
+        swap_grad_members(t->pass[w], s.pass[w]);
+    }
+    std::swap(t->z_new, s.z_new);
+}
+static void slot_swap_out(TrainState* t, RenderSlot& s) {
+    for (int w = 0; w < 2; ++w) {
+        swap_grad_members(t->pass[w], s.pass[w]);
+        std::swap(t->pass[w], s.pass[w]);
+    }
+    std::swap(t->z_new, s.z_new);
+}
+
+int render_forward_impl(nerf_ctx* c, int slot, const float* rays_o, const float* rays_d, int64_t N, int Sc, int Sf,
+                        const float* u_c, const float* u_f, uint64_t seed, int64_t ray_base, int mem) {
+    TrainState* t = c->train;
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
+    if (!rays_o || !rays_d) return fail("NULL argument");
+    if (slot < 0 || slot >= kMaxRenderSlots) return fail("slot %d out of range (0..%d)", slot, kMaxRenderSlots - 1);
+    if (N <= 0) return fail("need at least one ray (got %lld)", (long long)N);
+    if (Sc < 1 || Sc > 1024) return fail("bad coarse sample count %d", Sc);
+    const bool fine = Sf > 0 && t->net[1].present;
+    if (fine && Sc < 2) return fail("hierarchical sampling needs at least 2 coarse samples (got %d)", Sc);
+    if (fine && Sf > 256) return fail("training supports at most 256 fine samples per ray (got %d)", Sf);
+    if (fine && (sample_pdf_lds_bytes(Sc, Sf) > 64 * 1024 || sample_pdf_bwd_lds_bytes(Sc, Sf) > 64 * 1024))
+        return fail("Sc=%d Sf=%d exceeds the sampler's LDS budget", Sc, Sf);
+    if ((size_t)slot >= t->slots.size()) t->slots.resize((size_t)slot + 1);
+    RenderSlot& s = t->slots[slot];
+    s.valid = false;
+    const size_t f = sizeof(float);
+    // the slot keeps its own copies of the rays and draws: the caller's buffers need not outlive this call
+    auto keep = [&](DevBuf& b, const float* src, size_t bytes) -> int {
+        if (mem == NERF_MEM_HOST) return h2d(c, b, src, bytes);
+        if (int r = ensure(c, b, bytes)) return r;
+        HIP_OK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    };
+    if (int r = keep(s.o, rays_o, N * 4 * f)) return r;
+    if (int r = keep(s.d, rays_d, N * 4 * f)) return r;
+    s.has_uc = u_c != nullptr;
+    s.has_uf = fine && u_f != nullptr;
+    if (s.has_uc) if (int r = keep(s.u_c, u_c, (size_t)N * Sc * f)) return r;
+    if (s.has_uf) if (int r = keep(s.u_f, u_f, (size_t)N * Sf * f)) return r;
+    const float *o = (const float*)s.o.p, *d = (const float*)s.d.p;
+    const float* uc = s.has_uc ? (const float*)s.u_c.p : nullptr;
+    const float* uf = s.has_uf ? (const float*)s.u_f.p : nullptr;
+    const int Sm = Sc + Sf;
+    PassDims dc{N, Sc, N * Sc, (N * Sc + 127) / 128 * 128};
+    PassDims df{N, Sm, N * (long long)Sm, (N * (long long)Sm + 127) / 128 * 128};
+    slot_swap_in(t, s);
+    int r = ensure_pass(c, t->pass[0], dc);
+    if (fine) r |= ensure_pass(c, t->pass[1], df);
+    r |= ensure(c, t->z_new, (fine ? N * (long long)Sf : 1) * f);
+    if (!r) {
+        TPass& pc = t->pass[0];
+        launch_z_values(c->cfg.near_boundary, c->cfg.far_boundary, N, Sc, uc, seed, ray_base, (float*)pc.z.p, c->stream);
+        r = forward_pass(c, t, 0, dc, o, d);
+        if (!r && fine) {
+            launch_sample_pdf((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, ray_base, (float*)t->z_new.p,
+                              (float*)t->pass[1].z.p, c->stream);
+            r = forward_pass(c, t, 1, df, o, d);
+        }
+    }
+    slot_swap_out(t, s);
+    if (r) return r;
+    HIP_OK(hipGetLastError());
+    s.N = N; s.Sc = Sc; s.Sf = fine ? Sf : 0; s.seed = seed; s.ray_base = ray_base;
+    s.valid = true;
+    return 0;
+}
+
+int render_backward_impl(nerf_ctx* c, int slot, const float* d_rgb_in, bool accumulate, int mem) {
+    TrainState* t = c->train;
+    if (!t || !t->training) return fail("nerf_train_begin has not been called");
+    if (!d_rgb_in) return fail("NULL argument");
+    if (slot < 0 || (size_t)slot >= t->slots.size() || !t->slots[slot].valid)
+        return fail("slot %d holds no forward pass (nerf_train_render_forward first; a backward pass consumes it, and so does "
+                    "an optimizer step)", slot);
+    RenderSlot& s = t->slots[slot];
+    const long long N = s.N;
+    const int Sc = s.Sc, Sf = s.Sf;
+    const bool fine = Sf > 0;
+    const size_t f = sizeof(float);
+    const float* dr;
+    if (int r = stage_in(c, t->tgt, d_rgb_in, N * 3 * f, mem, &dr)) return r;
+    const int Sm = Sc + Sf;
+    PassDims dc{N, Sc, N * Sc, (N * Sc + 127) / 128 * 128};
+    PassDims df{N, Sm, N * (long long)Sm, (N * (long long)Sm + 127) / 128 * 128};
+    const long long Mmax = fine ? df.Mp : dc.Mp;
+    int r = ensure(c, t->Ga, Mmax * 256 * f);
+    r |= ensure(c, t->Gb, Mmax * 256 * f);
+    r |= ensure(c, t->G9, Mmax * 128 * f);
+    r |= ensure(c, t->Graw, Mmax * 4 * f);
+    r |= ensure(c, t->dsig, Mmax * f);
+    r |= ensure(c, t->dA0, Mmax * kXyzPad * f);
+    r |= ensure(c, t->partial, (size_t)2 * kTrainSplitsWide * (kLdC4 + 1) * 256 * f);
+    r |= ensure(c, t->d_wext, dc.M * f);
+    r |= ensure(c, t->d_zf, (fine ? N * (long long)Sf : 1) * f);
+    r |= ensure(c, t->d_zm, (fine ? df.M : 1) * f);
+    r |= ensure(c, t->zero_rgb, N * 3 * f);
+    r |= ensure(c, t->gmax, 2 * 16 * 64 * sizeof(unsigned));
+    if (t->mixed) {
+        r |= ensure(c, t->d_rgb, N * 3 * f);
+        if (accumulate)
+            for (int w = 0; w < 2; ++w)
+                if (t->net[w].present) r |= ensure(c, t->gsave[w], t->nblob * f);
+    }
+    if (r) return r;
+    float* Graw = (float*)t->Graw.p;
+    const bool through_sampler = fine && t->cfg.sampler_gradient != 0;
+    const bool computes[2] = {!fine || through_sampler, fine};
+    if (t->mixed) {                               // as render_gradients_impl: scale d_rgb on the device, unscale at the end
+        OptState* st = (OptState*)t->opt.p;
+        if (!accumulate) launch_opt_begin(st, c->stream);
+        launch_scale_by_loss_scale(dr, N * 3, st, (float*)t->d_rgb.p, c->stream);
+        dr = (const float*)t->d_rgb.p;
+        if (accumulate)
+            for (int w = 0; w < 2; ++w)
+                if (computes[w] && t->net[w].present)
+                    HIP_OK(hipMemcpyAsync(t->gsave[w].p, t->net[w].grad, t->nblob * f, hipMemcpyDeviceToDevice, c->stream));
+    }
+    t->acc_grads = accumulate && !t->mixed;
+    const float *o = (const float*)s.o.p, *d = (const float*)s.d.p;
+    const float* uf = s.has_uf ? (const float*)s.u_f.p : nullptr;
+    const uint64_t seed = s.seed;
+    const long long ray_base = s.ray_base;
+    slot_swap_in(t, s);
+    TPass& pc = t->pass[0];
+    int q = 0;
+    if (fine) {
+        TPass& pf = t->pass[1];
+        HIP_OK(hipMemsetAsync(Graw + df.M * 4, 0, (df.Mp - df.M) * 4 * f, c->stream));
+        float* d_zm = through_sampler ? (float*)t->d_zm.p : nullptr;
+        launch_composite_bwd((const float*)pf.raw.p, (const float*)pf.z.p, (const float*)pf.T.p, N, Sm, dr, nullptr, Graw, d_zm,
+                             c->stream);
+        q = backward_pass(c, t, 1, df, o, d, d_zm);
+        if (!q && through_sampler) {
+            launch_unmerge_grad((const float*)t->z_new.p, (const float*)pc.z.p, d_zm, N, Sc, Sf, (float*)t->d_zf.p, c->stream);
+            launch_sample_pdf_bwd((const float*)pc.w.p, (const float*)pc.z.p, N, Sc, Sf, uf, seed, ray_base,
+                                  (const float*)t->d_zf.p, (float*)t->d_wext.p, c->stream);
+            HIP_OK(hipMemsetAsync(t->zero_rgb.p, 0, N * 3 * f, c->stream));
+            HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
+            launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc,
+                                 (const float*)t->zero_rgb.p, (const float*)t->d_wext.p, Graw, nullptr, c->stream);
+            q = backward_pass(c, t, 0, dc, o, d, nullptr);
+        } else if (!q && !accumulate) {
+            HIP_OK(hipMemsetAsync(t->net[0].grad, 0, t->nblob * f, c->stream));   // render() does not depend on it
+        }
+    } else {
+        HIP_OK(hipMemsetAsync(Graw + dc.M * 4, 0, (dc.Mp - dc.M) * 4 * f, c->stream));
+        launch_composite_bwd((const float*)pc.raw.p, (const float*)pc.z.p, (const float*)pc.T.p, N, Sc, dr, nullptr, Graw, nullptr,
+                             c->stream);
+        q = backward_pass(c, t, 0, dc, o, d, nullptr);
+    }
+    t->acc_grads = false;
+    int qj = join_side(c, t);                     // (before the stash leaves TrainState::pass: the side stream reads it)
+    slot_swap_out(t, s);
+    s.valid = false;
+    if (q) return q;
+    if (qj) return qj;
+    if (t->mixed) {
+        float* g[2]; const float* add[2]; int n = 0;
+        for (int w = 0; w < 2; ++w)
+            if (computes[w] && t->net[w].present) {
+                g[n] = t->net[w].grad;
+                add[n] = accumulate ? (const float*)t->gsave[w].p : nullptr;
+                ++n;
+            }
+        launch_unscale_check(g[0], n > 1 ? g[1] : nullptr, t->nblob, (OptState*)t->opt.p, c->stream, false, add[0],
+                             n > 1 ? add[1] : nullptr);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int read_metrics(nerf_ctx* c, bool fine, float* metrics) {
     if (!metrics) return 0;
     float h[2] = {0.f, 0.f};
@@ -860,6 +1062,7 @@ int apply_impl(nerf_ctx* c) {
     // alone), then the training matrices are re-laid out from the blob either way
     TrainState* t = c->train;
     OptState* st = (OptState*)t->opt.p;
+    for (RenderSlot& sl : t->slots) sl.valid = false;      // kept activations belong to the weights that made them
     for (int w = 0; w < 2; ++w) {
         TNet& n = t->net[w];
         if (!n.present) continue;
@@ -895,7 +1098,12 @@ void train_free(nerf_ctx* c) {
     if (t->sidx) (void)hipFree(t->sidx);
     if (t->cidx) (void)hipFree(t->cidx);
     for (int32_t* bi : t->bidx) if (bi) (void)hipFree(bi);
-    TPass* passes[] = {&t->pass[0], &t->pass[1]};
+    std::vector<TPass*> passes = {&t->pass[0], &t->pass[1]};
+    for (RenderSlot& sl : t->slots) {
+        passes.push_back(&sl.pass[0]);
+        passes.push_back(&sl.pass[1]);
+        for (DevBuf* b : {&sl.o, &sl.d, &sl.u_c, &sl.u_f, &sl.z_new}) free_buf(*b);
+    }
     for (TPass* pp : passes) {
         TPass& p = *pp;
         DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
@@ -1153,6 +1361,53 @@ int nerf_train_render_gradients(nerf_ctx* c, const float* rays_orig, const float
         HIP_OK(hipMemcpyAsync(grad_fine, t->net[1].grad, t->nblob * sizeof(float), kind, c->stream));
     }
     if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int nerf_train_render_forward(nerf_ctx* c, int32_t slot, const float* rays_orig, const float* rays_dirs, int64_t N, int32_t Sc,
+                              int32_t Sf, const float* u_coarse, const float* u_fine, uint64_t seed, int64_t ray_base,
+                              float* rgb_out, int mem) {
+    ENTER(c);
+    if (int r = render_forward_impl(c, slot, rays_orig, rays_dirs, N, Sc, Sf, u_coarse, u_fine, seed, ray_base, mem)) return r;
+    const RenderSlot& s = c->train->slots[slot];
+    if (rgb_out) {
+        const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        HIP_OK(hipMemcpyAsync(rgb_out, s.pass[s.Sf > 0 ? 1 : 0].rgb.p, N * 3 * sizeof(float), kind, c->stream));
+    }
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int nerf_train_render_backward(nerf_ctx* c, int32_t slot, const float* d_rgb, int32_t accumulate, float* grad_coarse,
+                               float* grad_fine, int mem) {
+    ENTER(c);
+    const bool fine = c->train && slot >= 0 && (size_t)slot < c->train->slots.size() && c->train->slots[slot].Sf > 0;
+    if (grad_fine && !fine) return fail("grad_fine requested but slot %d ran no fine pass", slot);   // (before it is consumed)
+    if (int r = render_backward_impl(c, slot, d_rgb, accumulate != 0, mem)) return r;
+    TrainState* t = c->train;
+    const hipMemcpyKind kind = mem == NERF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (grad_coarse) HIP_OK(hipMemcpyAsync(grad_coarse, t->net[0].grad, t->nblob * sizeof(float), kind, c->stream));
+    if (grad_fine) HIP_OK(hipMemcpyAsync(grad_fine, t->net[1].grad, t->nblob * sizeof(float), kind, c->stream));
+    if (mem == NERF_MEM_HOST) HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int nerf_train_render_release(nerf_ctx* c) {
+    ENTER(c);
+    TrainState* t = c->train;
+    if (!t) return 0;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (t->side) HIP_OK(hipStreamSynchronize(t->side));
+    for (RenderSlot& sl : t->slots) {
+        for (TPass& p : sl.pass) {
+            DevBuf* bs[] = {&p.C4, &p.C8, &p.H1, &p.H2, &p.H3, &p.H5, &p.H6, &p.H7, &p.H8b, &p.H9, &p.raw, &p.T, &p.w,
+                            &p.rgb, &p.z, &p.masks, &p.dxa, &p.dxb, &p.rs};
+            for (DevBuf* b : bs) free_buf(*b);
+            for (DevBuf& b : p.D) free_buf(b);
+        }
+        for (DevBuf* b : {&sl.o, &sl.d, &sl.u_c, &sl.u_f, &sl.z_new}) free_buf(*b);
+    }
+    t->slots.clear();
     return 0;
 }
 

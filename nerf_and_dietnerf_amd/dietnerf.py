@@ -54,7 +54,7 @@ class DietNeRF(NeRF):
     def __init__(self, net_config: Dict, render_config: Dict, near_boundary: float, far_boundary: float, target_images,
                  target_camera_poses, field_of_view, max_steps_of_consistency_loss: int = -1, estimated_intersection=None,
                  rot_mat_to_in_front_of_point_of_interest=None, *, embedder: Optional[Callable] = None, device: int = 0,
-                 precision: str = "auto", seed: int = 0):
+                 precision: str = "auto", seed: int = 0, keep_activations: bool = True):
         import torch
         emb = embedder if embedder is not None else type(self).embedder   # (class attribute: set once for all models)
         if emb is None:
@@ -84,6 +84,10 @@ class DietNeRF(NeRF):
                                                          np.asarray(rot_mat_to_in_front_of_point_of_interest, np.float64))
         self.is_spherical_dataset = self.point_of_interest_in_scene is not None
         self.rng = np.random.default_rng(seed)
+        # True: the source image's activations stay in HBM between its forward and its backward (one forward, as under the
+        # reference's tape; 38 GB at 150 x 150 x (55 + 110) under the float32 policy, 19 GB under mixed_float16).  False: the
+        # image is rendered by the render path and every batch's forward is re-run under the tape (a few GB, ~20 % slower)
+        self.keep_activations = bool(keep_activations)
         self._extra_sums = None                  # device-side running sum of cosine_similarity_loss (+ step count)
         self.last_consistency = None             # target index, pose and seed of the latest consistency render
 
@@ -179,18 +183,27 @@ class DietNeRF(NeRF):
             target_image_embedding = self.target_images_embedding[rand_index]
         self.last_consistency = {"target_index": rand_index, "pose": pose, "seed": int(seed)}    # (for plots and tests)
         begin, count = ray_slab(s * s, rank, world)
-        # the image the embedder sees is the forward of the tape that is differentiated below: under mixed_float16 that
-        # tape runs the single-pass fp16 network, so the image is rendered in that arithmetic too (the reference has ONE
-        # forward, under its policy); same draws through (seed, global ray index)
-        keep = ctx.precision
-        if getattr(self, "_mixed", False) and keep != "f16":
-            ctx.set_precision("f16")
-        # (the reference renders in batch_size_train batches to bound TensorFlow's activation memory, src/DietNeRF.py:215-218;
-        # nothing per layer is materialised here and results do not depend on the batch: the library's own batch)
-        slab = ctx.render_image(pose, self.fov, s, s, 0, n_c, n_f, seed=seed, ray_begin=begin, ray_count=count,
-                                device_out=True, rgb_only=True)[0].reshape(-1, 3)
-        if ctx.precision != keep:
-            ctx.set_precision(keep)
+        pose_t = torch.as_tensor(pose, dtype=torch.float32, device=self._dev)
+        dirs = ctx.get_rays_directions(s, s, self.fov, pose_t).reshape(-1, 4)[begin:begin + count].contiguous()
+        orig = pose_t[:, 3].expand(count, 4).contiguous()
+        batch = int(self.batch_size_train)
+        if self.keep_activations:
+            # ONE forward, as under the reference's tape (src/DietNeRF.py:215-218): every batch of the image runs the trainer's
+            # forward into a slot of its own and stays there (nerf_train_render_forward); its rgb IS the image
+            slab = torch.cat([ctx.train_render_forward(k, orig[b:b + batch], dirs[b:b + batch], n_c, n_f, seed=seed,
+                                                       ray_base=begin + b)
+                              for k, b in enumerate(range(0, count, batch))])
+        else:
+            # the image is rendered by the render path and the forward re-run under the tape, batch by batch (bounded memory).
+            # Under mixed_float16 that tape runs the single-pass fp16 network, so the image is rendered in that arithmetic
+            # too; same draws through (seed, global ray index); the library's own batch (results do not depend on it)
+            keep = ctx.precision
+            if getattr(self, "_mixed", False) and keep != "f16":
+                ctx.set_precision("f16")
+            slab = ctx.render_image(pose, self.fov, s, s, 0, n_c, n_f, seed=seed, ray_begin=begin, ray_count=count,
+                                    device_out=True, rgb_only=True)[0].reshape(-1, 3)
+            if ctx.precision != keep:
+                ctx.set_precision(keep)
         flat = gather_slabs(slab, s * s, group) if world > 1 else slab
         img = flat.reshape(s, s, 3).detach().requires_grad_(True)
         source_image_embedding = self.embedder(self.embedder_preprocess(img[None]))[0]
@@ -200,15 +213,16 @@ class DietNeRF(NeRF):
         if world > 1:
             d_flat = d_flat * float(world)
         d_flat = d_flat.contiguous()
-        pose_t = torch.as_tensor(pose, dtype=torch.float32, device=self._dev)
-        dirs = ctx.get_rays_directions(s, s, self.fov, pose_t).reshape(-1, 4)[begin:begin + count].contiguous()
-        orig = pose_t[:, 3].expand(count, 4).contiguous()
         blobs = (None, None)
-        batch = int(self.batch_size_train)
-        for b in range(0, count, batch):
-            _, gc, gf = ctx.train_render_gradients(orig[b:b + batch], dirs[b:b + batch], d_flat[b:b + batch], n_c, n_f,
-                                                   seed=seed, ray_base=begin + b, accumulate=accumulate or b > 0)
-            blobs = (gc, gf)
+        starts = list(range(0, count, batch))
+        for k, b in enumerate(starts):
+            last = k == len(starts) - 1
+            if self.keep_activations:
+                blobs = ctx.train_render_backward(k, d_flat[b:b + batch], accumulate=accumulate or b > 0, want_blobs=last)
+            else:
+                _, gc, gf = ctx.train_render_gradients(orig[b:b + batch], dirs[b:b + batch], d_flat[b:b + batch], n_c, n_f,
+                                                       seed=seed, ray_base=begin + b, accumulate=accumulate or b > 0)
+                blobs = (gc, gf)
         return cs.detach(), blobs
 
     # ---- src/DietNeRF.py:120-157 ----

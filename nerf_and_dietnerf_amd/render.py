@@ -221,6 +221,7 @@ class Context:
         self._auto_fp32 = False      # "auto": this weight set overflowed fp16 once -> exact fp32 until the weights change
         self._auto_unchecked = False  # "auto": device-resident calls since the last look at the counter
         self.auto_fallbacks = 0      # "auto": calls that were re-rendered in exact fp32
+        self._slot_fine = {}         # train_render_forward slots that ran a fine pass
 
     def close(self):
         if getattr(self, "h", None):
@@ -461,6 +462,38 @@ class Context:
         _lib.check(self.lib.nerf_train_render_gradients(self.h, po, pd, pg, n, n_c, n_f, uc, uf, seed, ray_base,
                                                         1 if accumulate else 0, prgb, pgc, pgf, arr.mem))
         return rgb, gc, gf
+
+    def train_render_forward(self, slot: int, rays_orig, rays_dirs, n_c, n_f, u_coarse=None, u_fine=None, seed=0, ray_base=0):
+        """First half of ``train_render_gradients`` with the activations KEPT in ``slot`` (nerf_train_render_forward, ABI 5):
+        -> rgb (N,3) of this batch -- the forward of the tape itself.  For callers whose d_rgb needs the whole image first
+        (DietNeRF's embedding network): forward every batch into its own slot, build d_rgb, then ``train_render_backward``
+        per slot; the image is not rendered a second time.  An optimizer step invalidates all slots."""
+        arr = self._arrays(rays_orig, rays_dirs)
+        n = int(rays_orig.shape[0])
+        po, pd = arr.inp(rays_orig, (n, 4)), arr.inp(rays_dirs, (n, 4))
+        uc = arr.inp(u_coarse, (n, n_c)) if u_coarse is not None else None
+        uf = arr.inp(u_fine, (n, n_f)) if (u_fine is not None and n_f > 0) else None
+        rgb, prgb = arr.out((n, 3))
+        _lib.check(self.lib.nerf_train_render_forward(self.h, int(slot), po, pd, n, n_c, n_f, uc, uf, seed, ray_base, prgb,
+                                                      arr.mem))
+        self._slot_fine[int(slot)] = n_f > 0 and self.loaded[1]
+        return rgb
+
+    def train_render_backward(self, slot: int, d_rgb, accumulate=False, want_blobs=True):
+        """Second half: ``d_rgb`` (N,3) for the batch kept in ``slot`` -> (grad_coarse blob, grad_fine blob | None) copies (or
+        (None, None)); the gradients stay in / are added to the context's blobs exactly as ``train_render_gradients`` leaves
+        them (bit-identical).  Consumes the slot."""
+        arr = self._arrays(d_rgb)
+        pg = arr.inp(d_rgb)
+        fine = self._slot_fine.get(int(slot), False)
+        gc, pgc = arr.out((self.blob_size(),)) if want_blobs else (None, None)
+        gf, pgf = arr.out((self.blob_size(),)) if want_blobs and fine else (None, None)
+        _lib.check(self.lib.nerf_train_render_backward(self.h, int(slot), pg, 1 if accumulate else 0, pgc, pgf, arr.mem))
+        return gc, gf
+
+    def train_render_release(self) -> None:
+        """Frees the kept activations of every slot (they are grow-only otherwise; train_end frees them too)."""
+        _lib.check(self.lib.nerf_train_render_release(self.h))
 
     def train_apply(self, grad_coarse=None, grad_fine=None) -> None:
         """Adam update from the given gradient blobs (e.g. after an all-reduce), or from the ctx's own."""

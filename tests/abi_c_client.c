@@ -175,6 +175,26 @@ int main(int argc, char** argv) {
         }
         printf("dietnerf_mixed %g %lld %lld metric_steps %lld loss %.9g\n", scale, (long long)applied, (long long)skipped,
                (long long)steps, sums[0]);
+        /* ABI 5: the same step with the image's activations KEPT between forward and backward (one forward, as under the
+         * reference's tape): nerf_train_render_forward hands out the rgb the caller's embedding network sees, its d_rgb goes
+         * into nerf_train_render_backward of the same slot; a second backward on the consumed slot is refused */
+        float* rgb_fw = (float*)malloc(sizeof(float) * N * 3);
+        if (nerf_train_begin(ctx, &tm) ||
+            nerf_train_gradients(ctx, orig, dirs, tgt, N, 16, 16, NULL, NULL, 4u, NULL, NULL, NULL, NERF_MEM_HOST) ||
+            nerf_train_render_forward(ctx, 0, orig, dirs, N, 16, 16, NULL, NULL, 4u, 0, rgb_fw, NERF_MEM_HOST) ||
+            nerf_train_render_backward(ctx, 0, d_rgb, 1, NULL, NULL, NERF_MEM_HOST)) {
+            fprintf(stderr, "dietnerf slots: %s\n", nerf_last_error()); return 1;
+        }
+        const int consumed = nerf_train_render_backward(ctx, 0, d_rgb, 1, NULL, NULL, NERF_MEM_HOST) != 0;
+        if (nerf_train_apply(ctx, NULL, NULL, NERF_MEM_HOST) || nerf_train_loss_scale(ctx, &scale, &applied, &skipped) ||
+            nerf_train_render_release(ctx) || nerf_train_end(ctx)) {
+            fprintf(stderr, "dietnerf slots: %s\n", nerf_last_error()); return 1;
+        }
+        int finite_rgb = 1;
+        for (int i = 0; i < N * 3; ++i) finite_rgb &= rgb_fw[i] >= 0.f && rgb_fw[i] <= 1.f;
+        printf("dietnerf_slots %g %lld %lld consumed_refused %d rgb_in_range %d\n", scale, (long long)applied,
+               (long long)skipped, consumed, finite_rgb);
+        free(rgb_fw);
         free(d_rgb);
         free(dirs); free(orig); free(tgt);
     }

@@ -91,12 +91,15 @@ def _oracle_step(oracle, golden_ckpt, model, p, seed, alpha, **kw):
                                 targets[lc["target_index"]].numpy(), alpha=alpha, **kw), targets
 
 
+@pytest.mark.parametrize("keep", [True, False])
 @pytest.mark.parametrize("alpha", [1.0, 0.05])
-def test_dietnerf_step_gradients_match_autograd(oracle, golden_ckpt, alpha, capsys):
+def test_dietnerf_step_gradients_match_autograd(oracle, golden_ckpt, alpha, keep, capsys):
     """A consistency-loss step (counter = 13): metrics and the summed gradients of both networks against float64 autograd of
     the reference's train_step -- ray loss with the coarse MSE counted twice, plus 0.1 * (1 - cos) / 2 of the embeddings of
-    a 12x12 source render (8 + 8 samples, three 64-ray batches incl. a ragged last one) -- then one Adam step on the sum."""
-    model, data, p = _setup(oracle, golden_ckpt, alpha, mixed=False)
+    a 12x12 source render (8 + 8 samples, three 64-ray batches incl. a ragged last one) -- then one Adam step on the sum.
+    keep: the source image's activations stay resident between its one forward and its backward (the default), or the image
+    is rendered by the render path and each batch's forward re-run under the tape."""
+    model, data, p = _setup(oracle, golden_ckpt, alpha, mixed=False, keep_activations=keep)
     model.counter = 12
     metrics, used, (gc, gf) = model.compute_gradients(data, seed=77)
     assert used and model.counter == 13 and model.last_consistency["seed"] == 77 + 104729
@@ -113,7 +116,7 @@ def test_dietnerf_step_gradients_match_autograd(oracle, golden_ckpt, alpha, caps
     ec, ef = _relerr(gc, r["grad_coarse"]), _relerr(gf, r["grad_fine"])
     cc, cf = _cos(gc, r["grad_coarse"]), _cos(gf, r["grad_fine"])
     with capsys.disabled():
-        print(f"\n[DietNeRF consistency step, alpha {alpha:g}] gradients vs float64 autograd of src/DietNeRF.py:120-222: "
+        print(f"\n[DietNeRF consistency step, alpha {alpha:g}, activations {'kept' if keep else 're-computed'}] gradients vs float64 autograd of src/DietNeRF.py:120-222: "
               f"coarse {ec:.2e}, fine {ef:.2e} of max|g|; cosine {cc:.7f}, {cf:.7f}; consistency loss "
               f"{metrics['cosine_similarity_loss']:.5f}")
     # alpha = 1: 5e-4 instead of the train-step tests' 2e-4 -- half of the fine gradient comes through d(loss)/d(image), which
@@ -156,11 +159,12 @@ def test_dietnerf_plain_steps_use_the_doubled_coarse_term(oracle, golden_ckpt):
     model.ctx.close()
 
 
-def test_dietnerf_step_under_mixed_float16(oracle, golden_ckpt, capsys):
+@pytest.mark.parametrize("keep", [True, False])
+def test_dietnerf_step_under_mixed_float16(oracle, golden_ckpt, keep, capsys):
     """The policy the reference always runs DietNeRF under (src/ExecutionRun.py:220-221, LossScaleOptimizer :260-262): the
     summed gradients against the autograd oracle that rounds where the mixed_float16 kernels round (alpha = 1; bars of the
     train-step case: coarse 3e-2, fine 5e-3 of max|g|), ONE verdict over both losses, the step applied at the initial scale."""
-    model, data, p = _setup(oracle, golden_ckpt, 1.0, mixed=True)
+    model, data, p = _setup(oracle, golden_ckpt, 1.0, mixed=True, keep_activations=keep)
     model.counter = 12
     metrics, used, (gc, gf) = model.compute_gradients(data, seed=21)
     assert used

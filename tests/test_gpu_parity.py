@@ -658,6 +658,10 @@ def test_c_abi_client(tmp_path, oracle):
     dn = re.search(r"dietnerf_mixed (\S+) (\S+) (\S+) metric_steps (\S+) loss (\S+)", res.stdout)
     assert dn and (float(dn.group(1)), int(dn.group(2)), int(dn.group(3)), int(dn.group(4))) == (1024.0, 1, 0, 1), res.stdout
     assert 0 < float(dn.group(5)) < 10
+    # ABI 5 from C: the same step with the activations kept in a slot between nerf_train_render_forward and _backward
+    sl = re.search(r"dietnerf_slots (\S+) (\S+) (\S+) consumed_refused (\d) rgb_in_range (\d)", res.stdout)
+    assert sl and (float(sl.group(1)), int(sl.group(2)), int(sl.group(3)), sl.group(4), sl.group(5)) == (1024.0, 1, 0, "1", "1"), \
+        res.stdout
     # a communicator that cannot be created is SAID, and the client falls back to the single-rank render (what makes a first
     # real-RCCL N > 1 failure attributable): here provoked with a library path that does not exist
     env = dict(os.environ, NERF_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))

@@ -1249,6 +1249,75 @@ def test_backward_through_render_mixed_policy_other_variants(oracle, n_angles, c
     ctx.close()
 
 
+@pytest.mark.parametrize("policy", ["float32", "mixed_float16"])
+@pytest.mark.parametrize("n_angles", [2, 0])
+def test_render_forward_backward_slots_equal_the_one_call_path(oracle, golden_ckpt, policy, n_angles):
+    """nerf_train_render_forward / _backward (ABI 5): the graph of nerf_train_render_gradients in two calls with the activations
+    kept in a slot in between -- for DietNeRF, whose d_rgb exists only after the WHOLE image went through the embedding network.
+    Two ray batches of different sizes forwarded into two slots, then back-propagated: the rgb of each forward and the summed
+    gradients must equal the one-call path BIT FOR BIT (same kernels on the same operands), with explicit draws and with the
+    device generator (seed + ray_base), on top of ray-loss gradients (accumulate), under both policies; a consumed slot, a slot
+    invalidated by an optimizer step and a slot that was never filled are refused; slots can be released and refilled."""
+    import nerf_and_dietnerf_amd as N
+    mixed = policy == "mixed_float16"
+    pa = _problem(oracle, golden_ckpt, n=40, sc=55, sf=55, seed=9)
+    pb = _problem(oracle, golden_ckpt, n=33, sc=55, sf=55, seed=10)
+    if n_angles == 0:
+        for q in (pa, pb):
+            q["bc"], q["bf"] = N.glorot_blob(5, n_angles=0), N.glorot_blob(6, n_angles=0)
+    rng = np.random.default_rng(3)
+    da = (rng.standard_normal((40, 3)) * 0.1).astype(np.float32)
+    db = (rng.standard_normal((33, 3)) * 0.1).astype(np.float32)
+
+    def begin():
+        c = _ctx(pa, n_angles=n_angles)
+        c.train_begin(5e-4, mixed_float16=mixed)
+        return c
+
+    for explicit in (True, False):
+        ua = dict(u_coarse=pa["u_c"], u_fine=pa["u_f"]) if explicit else {}
+        ub = dict(u_coarse=pb["u_c"], u_fine=pb["u_f"]) if explicit else {}
+        kw_a, kw_b = dict(seed=7, ray_base=0, **ua), dict(seed=7, ray_base=40, **ub)
+        ref = begin()
+        ref.train_gradients(pa["o"], pa["d"], pa["tgt"], 55, 55, pa["u_c"], pa["u_f"])           # ray-loss gradients underneath
+        rgb_a, _, _ = ref.train_render_gradients(pa["o"], pa["d"], da, 55, 55, accumulate=True, **kw_a)
+        rgb_b, gc_ref, gf_ref = ref.train_render_gradients(pb["o"], pb["d"], db, 55, 55, accumulate=True, **kw_b)
+        ref.train_apply()
+        w_ref = ref.get_weights(1)
+        ref.close()
+        ctx = begin()
+        ctx.train_gradients(pa["o"], pa["d"], pa["tgt"], 55, 55, pa["u_c"], pa["u_f"])
+        np.testing.assert_array_equal(ctx.train_render_forward(0, pa["o"], pa["d"], 55, 55, **kw_a), rgb_a)
+        np.testing.assert_array_equal(ctx.train_render_forward(3, pb["o"], pb["d"], 55, 55, **kw_b), rgb_b)
+        ctx.train_render_backward(0, da, accumulate=True, want_blobs=False)
+        gc, gf = ctx.train_render_backward(3, db, accumulate=True)
+        np.testing.assert_array_equal(gc, gc_ref)
+        np.testing.assert_array_equal(gf, gf_ref)
+        with pytest.raises(RuntimeError, match="holds no forward"):
+            ctx.train_render_backward(3, db, accumulate=True)                                    # consumed
+        with pytest.raises(RuntimeError, match="holds no forward"):
+            ctx.train_render_backward(2, db)                                                     # never filled
+        ctx.train_apply()
+        np.testing.assert_array_equal(ctx.get_weights(1), w_ref)
+        assert ctx.train_loss_scale()[1:] == (1, 0)
+        # an optimizer step invalidates what was kept: the activations belong to the weights that made them
+        ctx.train_render_forward(0, pa["o"], pa["d"], 55, 55, **kw_a)
+        ctx.train_step(pa["o"], pa["d"], pa["tgt"], 55, 55, pa["u_c"], pa["u_f"], want_metrics=False)
+        with pytest.raises(RuntimeError, match="holds no forward"):
+            ctx.train_render_backward(0, da)
+        # accumulate = False starts a new gradient computation; a coarse-only slot; release and refill
+        r0 = ctx.train_render_forward(1, pa["o"], pa["d"], 55, 0, **{k: v for k, v in kw_a.items() if k != "u_fine"})
+        g0c, g0f = ctx.train_render_backward(1, da)
+        rr, g1c, _ = ctx.train_render_gradients(pa["o"], pa["d"], da, 55, 0, **{k: v for k, v in kw_a.items() if k != "u_fine"})
+        assert g0f is None
+        np.testing.assert_array_equal(r0, rr)
+        np.testing.assert_array_equal(g0c, g1c)
+        ctx.train_render_release()
+        ctx.train_render_forward(0, pb["o"], pb["d"], 55, 55, **kw_b)
+        ctx.train_render_backward(0, db)
+        ctx.close()
+
+
 def test_abi3_entry_points_fail_loudly(oracle, golden_ckpt):
     """nerf_host_alloc / nerf_host_free / nerf_train_get_gradients: argument errors are statuses + messages, never aborts."""
     import ctypes as C

@@ -41,39 +41,51 @@ def timed(label, f, acc):
     return out
 
 
-for rep in range(3):
-    acc = {}
-    timed("ray-loss gradients (nerf_train_gradients)", lambda: ctx.train_gradients(o, d, t, SC, SF, seed=rep, want_metrics=False,
-                                                                                  want_blobs=False), acc)
-    s = dn.IMG_SIZE_FOR_CS_LOSS
-    pose = dn.sample_random_source_pose()
-    keep = ctx.precision
-    if mixed:
-        timed("set_precision", lambda: ctx.set_precision("f16"), acc)
-    img = timed("source render 150x150 x (55+55)", lambda: ctx.render_image(pose, FOV, s, s, 2048, 55, 55, seed=9, device_out=True,
-                                                                          rgb_only=True)[0], acc)
-    if mixed:
-        timed("set_precision", lambda: ctx.set_precision(keep), acc)
+for keep in (False, True):
+    for rep in range(3):
+        acc = {}
+        timed("ray-loss gradients (nerf_train_gradients)", lambda: ctx.train_gradients(o, d, t, SC, SF, seed=rep, want_metrics=False,
+                                                                                      want_blobs=False), acc)
+        s = dn.IMG_SIZE_FOR_CS_LOSS
+        pose = dn.sample_random_source_pose()
+        pose_t = torch.as_tensor(pose, device="cuda")
+        dirs = timed("rays of the pose", lambda: ctx.get_rays_directions(s, s, FOV, pose_t).reshape(-1, 4), acc)
+        orig = pose_t[:, 3].expand(s * s, 4).contiguous()
+        starts = list(range(0, s * s, 2048))
+        if keep:
+            img = timed("forward of the 11 batches, activations kept (nerf_train_render_forward)", lambda: torch.cat(
+                [ctx.train_render_forward(k, orig[b:b + 2048], dirs[b:b + 2048], 55, 55, seed=9, ray_base=b)
+                 for k, b in enumerate(starts)]), acc)
+        else:
+            prec = ctx.precision
+            if mixed:
+                ctx.set_precision("f16")
+            img = timed("source render 150x150 x (55+55) (nerf_render_image)", lambda: ctx.render_image(
+                pose, FOV, s, s, 0, 55, 55, seed=9, device_out=True, rgb_only=True)[0], acc)
+            if mixed:
+                ctx.set_precision(prec)
 
-    def embed():
-        x = img.reshape(s, s, 3).detach().requires_grad_(True)
-        cs = 0.1 * dn.consistency_loss(emb(dn.embedder_preprocess(x[None]))[0], dn.target_images_embedding[0])
-        return torch.autograd.grad(cs, x)[0].reshape(-1, 3).contiguous()
-    d_img = timed("embedder forward + d(loss)/d(image) (caller's network: stand-in)", embed, acc)
-    pose_t = torch.as_tensor(pose, device="cuda")
-    dirs = timed("rays of the pose", lambda: ctx.get_rays_directions(s, s, FOV, pose_t).reshape(-1, 4), acc)
-    orig = pose_t[:, 3].expand(s * s, 4).contiguous()
+        def embed():
+            x = img.reshape(s, s, 3).detach().requires_grad_(True)
+            cs = 0.1 * dn.consistency_loss(emb(dn.embedder_preprocess(x[None]))[0], dn.target_images_embedding[0])
+            return torch.autograd.grad(cs, x)[0].reshape(-1, 3).contiguous()
+        d_img = timed("embedder forward + d(loss)/d(image) (caller's network: stand-in)", embed, acc)
 
-    def backward():
-        for b in range(0, s * s, 2048):
-            ctx.train_render_gradients(orig[b:b + 2048], dirs[b:b + 2048], d_img[b:b + 2048], 55, 55, seed=9, ray_base=b,
-                                       accumulate=True)
-    timed("backward through NeRF.render, 11 batches (nerf_train_render_gradients)", backward, acc)
-    timed("Adam (nerf_train_apply)", ctx.train_apply, acc)
-    if rep == 2:
-        print(f"# DietNeRF consistency step, {'mixed_float16' if mixed else 'float32'} policy, 2048-ray batch x (64 + 128) + 150x150 x "
-              f"(55 + 55) source image")
-        for k, v in acc.items():
-            print(f"{v:9.2f} ms  {k}")
-        print(f"{sum(acc.values()):9.2f} ms  total")
+        def backward():
+            for k, b in enumerate(starts):
+                if keep:
+                    ctx.train_render_backward(k, d_img[b:b + 2048], accumulate=True, want_blobs=False)
+                else:
+                    ctx.train_render_gradients(orig[b:b + 2048], dirs[b:b + 2048], d_img[b:b + 2048], 55, 55, seed=9, ray_base=b,
+                                               accumulate=True)
+        timed("backward through NeRF.render, 11 batches (" + ("nerf_train_render_backward" if keep else
+                                                              "nerf_train_render_gradients: forward re-run + backward") + ")",
+              backward, acc)
+        timed("Adam (nerf_train_apply)", ctx.train_apply, acc)
+        if rep == 2:
+            print(f"# DietNeRF consistency step, {'mixed_float16' if mixed else 'float32'} policy, 2048-ray batch x (64 + 128) + "
+                  f"150x150 x (55 + 55) source image; activations {'KEPT between forward and backward' if keep else 're-computed'}")
+            for k, v in acc.items():
+                print(f"{v:9.2f} ms  {k}")
+            print(f"{sum(acc.values()):9.2f} ms  total")
 ctx.close()
