@@ -1408,6 +1408,7 @@ int nerf_train_render_release(nerf_ctx* c) {
         for (DevBuf* b : {&sl.o, &sl.d, &sl.u_c, &sl.u_f, &sl.z_new}) free_buf(*b);
     }
     t->slots.clear();
+    (void)hipGetLastError();      // (a failed allocation while filling slots is what usually brings a caller here: start clean)
     return 0;
 }
 

@@ -187,13 +187,22 @@ class DietNeRF(NeRF):
         dirs = ctx.get_rays_directions(s, s, self.fov, pose_t).reshape(-1, 4)[begin:begin + count].contiguous()
         orig = pose_t[:, 3].expand(count, 4).contiguous()
         batch = int(self.batch_size_train)
+        slab = None
         if self.keep_activations:
             # ONE forward, as under the reference's tape (src/DietNeRF.py:215-218): every batch of the image runs the trainer's
             # forward into a slot of its own and stays there (nerf_train_render_forward); its rgb IS the image
-            slab = torch.cat([ctx.train_render_forward(k, orig[b:b + batch], dirs[b:b + batch], n_c, n_f, seed=seed,
-                                                       ray_base=begin + b)
-                              for k, b in enumerate(range(0, count, batch))])
-        else:
+            try:
+                slab = torch.cat([ctx.train_render_forward(k, orig[b:b + batch], dirs[b:b + batch], n_c, n_f, seed=seed,
+                                                           ray_base=begin + b)
+                                  for k, b in enumerate(range(0, count, batch))])
+            except RuntimeError as e:
+                if "out of memory" not in str(e).lower():
+                    raise
+                # the image's activations do not fit beside what else lives on this device: free the slots and go on with
+                # the two-forward path for the rest of this model's life (a few GB)
+                ctx.train_render_release()
+                self.keep_activations = False
+        if slab is None:
             # the image is rendered by the render path and the forward re-run under the tape, batch by batch (bounded memory).
             # Under mixed_float16 that tape runs the single-pass fp16 network, so the image is rendered in that arithmetic
             # too; same draws through (seed, global ray index); the library's own batch (results do not depend on it)

@@ -382,3 +382,31 @@ def test_dietnerf_without_a_fine_network(oracle, golden_ckpt, capsys):
     assert abs(metrics["loss"] - (r["loss"] + r["cosine_similarity_loss"])) <= 5e-6 * r["loss"]
     model.ctx.train_apply()
     model.ctx.close()
+
+
+def test_dietnerf_falls_back_when_the_activations_do_not_fit(oracle, golden_ckpt):
+    """keep_activations needs the source image's activations in HBM (38 / 19 GB at the reference's constants).  An allocation
+    that fails while the slots are filled (simulated: the third forward raises the library's out-of-memory error) releases the
+    slots and finishes THIS step -- and every later one -- on the two-forward path, with the same gradients as a model that
+    was built with keep_activations=False."""
+    model, data, p = _setup(oracle, golden_ckpt, 1.0, mixed=False)
+    ref, data_r, _ = _setup(oracle, golden_ckpt, 1.0, mixed=False, keep_activations=False)
+    model.counter = ref.counter = 12
+    real, calls = model.ctx.train_render_forward, []
+
+    def failing(slot, *a, **k):
+        calls.append(slot)
+        if len(calls) == 3:
+            raise RuntimeError("hipMalloc(&b.p, want) failed: out of memory (nerf_api.hip:43)")
+        return real(slot, *a, **k)
+    model.ctx.train_render_forward = failing
+    _, used, (gc, gf) = model.compute_gradients(data, seed=77)
+    _, _, (rc, rf) = ref.compute_gradients(data_r, seed=77)
+    assert used and calls == [0, 1, 2] and model.keep_activations is False
+    np.testing.assert_array_equal(gc.cpu().numpy(), rc.cpu().numpy())
+    np.testing.assert_array_equal(gf.cpu().numpy(), rf.cpu().numpy())
+    model.ctx.train_apply()
+    model.counter = 25
+    model.compute_gradients(data, seed=78)                     # the next consistency step does not try the slots again
+    assert calls == [0, 1, 2]
+    model.ctx.close(); ref.ctx.close()
