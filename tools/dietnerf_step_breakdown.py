@@ -13,6 +13,7 @@ import nerf_and_dietnerf_amd as N                      # noqa: E402
 from bench import FAR, FOV, NEAR, SC, SF, sphere_matrix  # noqa: E402
 
 mixed = len(sys.argv) > 1 and sys.argv[1] == "mixed"
+CSB = int(sys.argv[2]) if len(sys.argv) > 2 else 2048        # rays per batch of the consistency image
 net_cfg = {"hidden_layer_dim": 256, "last_hidden_layer_dim": 128, "leaky_relu_alpha": 0.05, "n_pos_enc_dim_xyz": 5,
            "n_pos_enc_view_dir": 4, "n_angles_for_model": 2, "n_rays_in_batch_train": 2048, "n_rays_in_batch_render": 4096}
 conv = torch.nn.Conv2d(3, 16, 16, 16).cuda()
@@ -51,10 +52,10 @@ for keep in (False, True):
         pose_t = torch.as_tensor(pose, device="cuda")
         dirs = timed("rays of the pose", lambda: ctx.get_rays_directions(s, s, FOV, pose_t).reshape(-1, 4), acc)
         orig = pose_t[:, 3].expand(s * s, 4).contiguous()
-        starts = list(range(0, s * s, 2048))
+        starts = list(range(0, s * s, CSB))
         if keep:
-            img = timed("forward of the 11 batches, activations kept (nerf_train_render_forward)", lambda: torch.cat(
-                [ctx.train_render_forward(k, orig[b:b + 2048], dirs[b:b + 2048], 55, 55, seed=9, ray_base=b)
+            img = timed(f"forward of the {len(starts)} batches, activations kept (nerf_train_render_forward)", lambda: torch.cat(
+                [ctx.train_render_forward(k, orig[b:b + CSB], dirs[b:b + CSB], 55, 55, seed=9, ray_base=b)
                  for k, b in enumerate(starts)]), acc)
         else:
             prec = ctx.precision
@@ -74,17 +75,17 @@ for keep in (False, True):
         def backward():
             for k, b in enumerate(starts):
                 if keep:
-                    ctx.train_render_backward(k, d_img[b:b + 2048], accumulate=True, want_blobs=False)
+                    ctx.train_render_backward(k, d_img[b:b + CSB], accumulate=True, want_blobs=False)
                 else:
-                    ctx.train_render_gradients(orig[b:b + 2048], dirs[b:b + 2048], d_img[b:b + 2048], 55, 55, seed=9, ray_base=b,
+                    ctx.train_render_gradients(orig[b:b + CSB], dirs[b:b + CSB], d_img[b:b + CSB], 55, 55, seed=9, ray_base=b,
                                                accumulate=True)
-        timed("backward through NeRF.render, 11 batches (" + ("nerf_train_render_backward" if keep else
+        timed(f"backward through NeRF.render, {len(starts)} batches (" + ("nerf_train_render_backward" if keep else
                                                               "nerf_train_render_gradients: forward re-run + backward") + ")",
               backward, acc)
         timed("Adam (nerf_train_apply)", ctx.train_apply, acc)
         if rep == 2:
             print(f"# DietNeRF consistency step, {'mixed_float16' if mixed else 'float32'} policy, 2048-ray batch x (64 + 128) + "
-                  f"150x150 x (55 + 55) source image; activations {'KEPT between forward and backward' if keep else 're-computed'}")
+                  f"150x150 x (55 + 55) source image in {CSB}-ray batches; activations {'KEPT between forward and backward' if keep else 're-computed'}")
             for k, v in acc.items():
                 print(f"{v:9.2f} ms  {k}")
             print(f"{sum(acc.values()):9.2f} ms  total")
