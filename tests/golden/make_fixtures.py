@@ -106,6 +106,23 @@ def copy_dataset(dst):
     np.save(os.path.join(os.path.dirname(dst), "alexander50_recorded_psnrs.npy"), psn.astype(np.float32))
 
 
+# configuration files copied as DATA (tests/golden/configs/; read by tests/test_config_host.py and tests/test_gpu_dietnerf.py):
+# BASELINE configs[0] -- from config_files/ and as the shipped run kept it in its save directory --, [2], [3], the
+# few-views DietNeRF variant and the xyz-only robot variant
+CONFIGS = ["50px_alexander_71pics_sphere_nerf", "256px_robot_72pics_sphere", "256px_alexander_71pics_sphere_dietnerf",
+           "256px_alexander_71pics_sphere_dietnerf_use5pics", "256px_robot_72pics_sphere_0angle"]
+
+
+def copy_configs(dst):
+    import shutil
+    os.makedirs(dst, exist_ok=True)
+    for name in CONFIGS:
+        shutil.copyfile(os.path.join(REF, "config_files", name + ".yaml"), os.path.join(dst, name + ".yaml"))
+    shutil.copyfile(os.path.join(RUN, "50px_alexander_71pics_sphere_nerf.yaml"),
+                    os.path.join(dst, "50px_alexander_71pics_sphere_nerf_save_dir_4.yaml"))
+
+
 if __name__ == "__main__":
     copy_dataset(os.path.join(os.path.dirname(__file__), "alexander50"))
+    copy_configs(os.path.join(os.path.dirname(__file__), "configs"))
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "alexander50_epoch095.npz"))
