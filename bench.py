@@ -300,73 +300,69 @@ def main():
 
     gather_check = None
     c_check_hung = False          # a worker thread is still blocked inside RCCL: leave through os._exit at the end
-    # (also under the one-GPU rehearsal -- BENCH_BACKEND=gloo with NERF_RCCL_LIB naming tests/stub_rccl.c's stand-in, the only
-    # way two ranks can share a device -- so that this check itself has run before the driver's first real N > 1 launch)
-    if world > 1 and (backend == "nccl" or os.environ.get("NERF_RCCL_LIB")):
-        # the two assemblies of the frame (torch collective vs the library's own ncclAllGather) must agree bit for bit.
-        # A mismatch fails the run loudly; a C-level communicator that cannot be created (it is a second RCCL
-        # communicator beside torch's) is reported and the run goes on with the torch collective.
-        # The second communicator has never met real peers on this pool (one-GPU boxes): its creation and first collective run in
-        # a worker thread under a wall-clock limit (BENCH_C_CHECK_TIMEOUT seconds, default 120), so that a hang there costs the
-        # cross-check, not the run -- the timed region below uses torch's collective unless --c-gather asks otherwise.
-        # The check runs on a context of ITS OWN (same weights, own stream): a ctx is single-caller, and the main thread must be
-        # free to go on with `model.ctx` if the worker never comes back.
-        box = {}
-        chk = model.ctx
-        if not c_gather:
-            chk = N.Context(near=NEAR, far=FAR, n_angles=2, precision=args.precision, device=dev_index)
-            chk.load_weights(0, blob_c); chk.load_weights(1, blob_f)
+    c_check_ran = False           # the second communicator was attempted in this process: no torch teardown afterwards
+    c_check_rc = 0
 
-        def c_level_frame(uid):
+    def c_level_check(chk, need_init):
+        """The two assemblies of the frame -- torch's collective and the library's own ncclAllGather
+        (nerf_render_image_sharded) -- must agree bit for bit.  The library's communicator is a SECOND RCCL communicator
+        beside torch's and has never met real peers on this pool (one-GPU boxes; the rehearsals use tests/stub_rccl.c), so
+        everything that touches it runs in a worker thread under a wall-clock limit (BENCH_C_CHECK_TIMEOUT seconds, default
+        120): a communicator that cannot be created is reported, one that never returns costs the check -- and, since
+        round 4, NOTHING ELSE: without --c-gather the check runs AFTER every measurement and after the last torch
+        collective this run needs, so even a second communicator that wedges the device cannot take the scaling
+        numbers with it.  -> (check string, hung, mismatch)"""
+        # torch's assembly first, in the main thread (needs nothing from the library's communicator)
+        b_img = N.gather_slabs(model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=12345, ray_begin=begin,
+                                                  ray_count=count, device_out=True, rgb_only=True)[0], total)
+        uid = None
+        if need_init:
+            ids = [chk.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            uid = ids[0]
+        torch.cuda.synchronize()
+        box = {}
+
+        def c_level_frame():
             try:
                 if os.environ.get("BENCH_C_CHECK_TEST_HANG") == "1":     # test hook: a call that never returns (touches nothing)
                     threading.Event().wait()
                 torch.cuda.set_device(dev_index)                 # (torch's current device is per thread)
                 if uid is not None:
                     chk.comm_init(uid, rank, world)
-                img_c = chk.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=12345, device_out=True)
+                a_img = chk.render_image_sharded(c2w, FOV, H, W, 1 << 18, SC, SF, seed=12345, device_out=True)
                 chk.synchronize()
                 torch.cuda.synchronize()
-                box["img"] = img_c
+                box["equal"] = bool(torch.equal(a_img.reshape(-1, 3), b_img.reshape(-1, 3)))
+                if not box["equal"]:
+                    box["diff"] = float((a_img.reshape(-1, 3) - b_img.reshape(-1, 3)).abs().max())
             except Exception as e:                               # noqa: BLE001
                 box["err"] = e
 
-        uid = None
-        if not c_gather:                                         # (--c-gather created the communicator above)
-            ids = [chk.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            uid = ids[0]
-        worker = threading.Thread(target=c_level_frame, args=(uid,), daemon=True)
+        worker = threading.Thread(target=c_level_frame, daemon=True)
         worker.start()
         worker.join(float(os.environ.get("BENCH_C_CHECK_TIMEOUT", "120")))
-        a_img = box.get("img")
         if worker.is_alive():
-            if c_gather:
-                raise SystemExit(f"rank {rank}: the library's RCCL communicator did not come up within the time limit")
-            c_check_hung = True
-            a_img = None
-            gather_check = "c-level communicator / first ncclAllGather did not return within the time limit; torch all-gather only"
-        elif "err" in box:
-            if c_gather:
-                raise box["err"]
+            return ("c-level communicator / first ncclAllGather did not return within the time limit; torch all-gather "
+                    "only"), True, False
+        if "err" in box:
             e = box["err"]
-            a_img = None
-            gather_check = f"c-level communicator unavailable ({type(e).__name__}: {e}); torch all-gather only"
-        # every rank takes the same branch below (the comparison contains a collective): all or none
-        ok_all = torch.tensor([1 if a_img is not None else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-        if int(ok_all.item()) == 0 and a_img is not None:
-            a_img = None
-            gather_check = "c-level communicator unavailable on another rank; torch all-gather only"
-        if a_img is not None:
-            b_img = N.gather_slabs(model.render_image(c2w, FOV, H, W, batch_size_input=1 << 18, seed=12345,
-                                                      ray_begin=begin, ray_count=count, device_out=True,
-                                                      rgb_only=True)[0], total)
-            if not torch.equal(a_img.reshape(-1, 3), b_img.reshape(-1, 3)):
-                raise SystemExit(f"rank {rank}: nerf_render_image_sharded (RCCL inside the library) and the torch "
-                                 f"all-gather assemble different frames "
-                                 f"(max diff {float((a_img.reshape(-1, 3) - b_img).abs().max())})")
-            gather_check = "c-level ncclAllGather image == torch all_gather image, bit for bit (checked in warm-up)"
+            return f"c-level communicator unavailable ({type(e).__name__}: {e}); torch all-gather only", False, False
+        if not box["equal"]:
+            return (f"MISMATCH: nerf_render_image_sharded (RCCL inside the library) and the torch all-gather assemble "
+                    f"different frames on rank {rank} (max diff {box['diff']})"), False, True
+        return "c-level ncclAllGather image == torch all_gather image, bit for bit", False, False
+
+    if c_gather:
+        # --c-gather times the library's own collective: its communicator exists already (comm_init_from_torch above) and
+        # has to be proven before the timed region; a failure here fails the run
+        gather_check, c_check_hung, bad = c_level_check(model.ctx, False)
+        c_check_ran = True
+        if c_check_hung or bad or "unavailable" in gather_check:
+            sys.stderr.write(f"rank {rank}: {gather_check}\n")
+            sys.stderr.flush()
+            os._exit(3)
+        gather_check += " (checked in warm-up)"
 
     for i in range(args.warmup):
         img = step(i)
@@ -427,6 +423,17 @@ def main():
     assert bool(torch.isfinite(img).all()) and tuple(img.shape[-1:]) == (3,)
     if args.rehearse_world > 1:
         args.no_cpu_baseline = True
+    # (also under the one-GPU rehearsal -- BENCH_BACKEND=gloo with NERF_RCCL_LIB naming tests/stub_rccl.c's stand-in, the only
+    # way two ranks can share a device -- so that this check itself has run before the driver's first real N > 1 launch)
+    if world > 1 and not c_gather and (backend == "nccl" or os.environ.get("NERF_RCCL_LIB")):
+        # every measurement is taken and every torch collective this run needs is behind us: now the library's own
+        # communicator may be tried, on a context of ITS OWN (same weights, own stream; a ctx is single-caller)
+        chk = N.Context(near=NEAR, far=FAR, n_angles=2, precision=args.precision, device=dev_index)
+        chk.load_weights(0, blob_c); chk.load_weights(1, blob_f)
+        gather_check, c_check_hung, bad = c_level_check(chk, True)
+        c_check_ran = True
+        c_check_rc = 1 if bad else 0
+        gather_check += " (checked after the timed region)"
 
     def roof(kernel, rows, ms, dtype_key):
         a = rows * FLOPS_PER_ROW / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -812,10 +819,14 @@ def main():
                 out["parity_check"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        if c_check_hung:          # do not run RCCL's teardown beside a call that never returned
+        if c_check_ran and not c_gather:
+            # a second communicator was tried in this process (and may have failed or hung on this or another rank): no
+            # barrier, no RCCL teardown -- every rank leaves by itself; the line is out
+            if c_check_rc:
+                sys.stderr.write(f"rank {rank}: {gather_check}\n")
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(c_check_rc)
+        dist.barrier()
         dist.destroy_process_group()
 
 
