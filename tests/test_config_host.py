@@ -64,7 +64,6 @@ def test_get_data_and_train_split_on_the_shipped_dataset(golden_ckpt):
 def test_blender_config_scales_its_bounds(golden_ckpt):
     """configs[2]: the Blender rig's near / far come from the YAML times the spherify scale (src/UtilsFiles.py:61-63)."""
     c = C.load_config(os.path.join(CFG, "256px_robot_72pics_sphere.yaml"))
-    poses, fov, near, far = None, None, None, None
     out = N.get_data_from_blender(os.path.join(HERE, "golden", "robot256"), c[C.RENDER][C.NEAR_DEPTH_RENDER],
                                   c[C.RENDER][C.FAR_DEPTH_RENDER], load_images=False)
     _, poses, fov, near, far = out[:5]

@@ -354,7 +354,6 @@ def test_dietnerf_without_a_fine_network(oracle, golden_ckpt, capsys):
     """n_render_samples_fine = 0 (src/NeRF.py:36-39; src/DietNeRF.py:166: `if self.model_fine`): the ray loss is MSE_c alone --
     no doubled term -- and the consistency loss reaches the coarse network directly, through its own render."""
     import torch
-    import nerf_and_dietnerf_amd as N
     from oracle import train_oracle as T
     model, data, p = _setup(oracle, golden_ckpt, 1.0, mixed=False, sf=0)
     assert model.model_fine is None
