@@ -15,7 +15,8 @@ from .keras_h5 import load_nerf_checkpoint, read_keras_weights, save_nerf_checkp
 from .sharding import allreduce_mean, dist_world, gather_slabs, ray_slab, render_image_sharded
 from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
 from .dietnerf import DietNeRF
-from . import config
+from . import config, scene
+from .scene import estimate_point_of_interest_in_scene
 from .config import get_nerf, get_num_of_batches, get_train_data, load_config
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
                        poses_avg, recenter_poses, spherify_poses)

@@ -8,8 +8,8 @@
                                                                  mixed_float16 policy, weights of starting_epoch_number if saved
 
 Not here (the reference's control plane): the task list, save-directory naming, plots, videos-to-disk,
-GCS sync.  ``estimate_point_of_interest_in_scene`` (RANSAC over the camera axes, src/UtilsCV.py) is out of scope as well:
-its result enters ``get_nerf`` as an argument (None = the non-spherical pose sampling of src/DietNeRF.py:254-260).
+GCS sync.  The scene analysis ``_init_dietnerf`` runs on the camera poses (where do the cameras look, is the rig spherical:
+src/ExecutionRun.py:249-254) is scene.py's ``estimate_point_of_interest_in_scene``.
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ from typing import Callable, Dict, Optional, Tuple
 import numpy as np
 
 from .datasets import get_data_from_blender, get_data_from_colmap, get_train_images_indices
+from .scene import estimate_point_of_interest_in_scene
 
 # key names, src/ConfigurationKeys.py
 DATASET_TYPE, DATASET_LOCATION = "dataset_type", "dataset_location"
@@ -32,6 +33,7 @@ N_EPOCHS, OPTIMIZER_LR, TEST_IMG_IDX = "n_epochs", "optimizer_lr", "test_img_idx
 N_RAYS_IN_BATCH_TRAIN = "n_rays_in_batch_train"
 BLENDER, COLMAP = "blender", "colmap"
 MIXED_FLOAT16 = "mixed_float16"
+ESTIMATE = "estimate"              # get_nerf(estimated_intersection=...): run the scene analysis, as the reference does
 
 
 def load_config(config_file_path) -> Dict:
@@ -73,12 +75,14 @@ def get_num_of_batches(n_rays_in_batch: int, n_c2w_mats: int, h: int, w: int) ->
 
 def get_nerf(config: Dict, near_boundary: float, far_boundary: float, *, images=None, camera_poses=None,
              field_of_view: Optional[float] = None, save_location=None, embedder: Optional[Callable] = None,
-             estimated_intersection=None, policy: str = MIXED_FLOAT16, device: int = 0, precision: str = "auto", **kw):
+             estimated_intersection=ESTIMATE, policy: str = MIXED_FLOAT16, device: int = 0, precision: str = "auto", **kw):
     """``ExecutionRun.get_nerf`` (src/ExecutionRun.py:216-232): a compiled NeRF -- or, for ``type_of_model: DietNeRF``
     (``_init_dietnerf``, :234-262; needs the dataset and an ``embedder``), a compiled DietNeRF whose consistency loss is
     limited to 95 % of the remaining training steps -- with the weights of ``starting_epoch_number`` loaded when
     ``save_location`` holds them.  ``policy``: the reference always trains under "mixed_float16" (:220-221); "float32" selects
-    the fp32-class trainer."""
+    the fp32-class trainer.  ``estimated_intersection``: ESTIMATE (default) runs the reference's scene analysis on ALL camera
+    poses (:249-251: the point the optical axes meet in, used only if the rig is spherical); an explicit point, or None
+    for the non-spherical pose sampling (src/DietNeRF.py:254-260), overrides it."""
     from .dietnerf import DietNeRF
     from .render import NeRF
     net, render, training = config[NEURAL_NET], config[RENDER], config[TRAINING]
@@ -91,6 +95,9 @@ def get_nerf(config: Dict, near_boundary: float, far_boundary: float, *, images=
         h, w = int(images[0].shape[0]), int(images[0].shape[1])
         n_batches = get_num_of_batches(net[N_RAYS_IN_BATCH_TRAIN], len(train_images), h, w)
         n_steps = n_batches * (training[N_EPOCHS] - epoch) * DietNeRF.PERCENTAGE_OF_TRAIN_STEPS_WITH_CONSISTENCY_LOSS
+        if isinstance(estimated_intersection, str) and estimated_intersection == ESTIMATE:
+            estimated_intersection, is_spherical_dataset = estimate_point_of_interest_in_scene(camera_poses)
+            estimated_intersection = estimated_intersection if is_spherical_dataset else None
         rot = None
         if estimated_intersection is not None:              # :250-254: the test view's rotation faces the scene
             rot = np.eye(4)

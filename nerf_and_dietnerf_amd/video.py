@@ -143,9 +143,9 @@ def get_rotation_matrix_from_source_to_dest_mats(source_mat: np.ndarray, dest_ma
 
 # ---------------------------------------------------------------------------------------------
 # the three camera tours of ExecutionRun (src/ExecutionRun.py:358-437).  The reference decides between its
-# "spherical" and "forward-facing" branches with a randomised scene analysis (RANSAC point of interest,
-# src/UtilsCV.py:440-464); that analysis is a pose utility outside this package, so its two results
-# (`is_spherical_dataset`, `estimated_intersection`) are arguments here.
+# "spherical" and "forward-facing" branches with a scene analysis (consensus point of interest of the optical axes,
+# src/UtilsCV.py:440-464 -> scene.estimate_point_of_interest_in_scene); its two results (`is_spherical_dataset`,
+# `estimated_intersection`) are arguments here.
 # ---------------------------------------------------------------------------------------------
 def get_l_to_r_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: int, fps_render_video: int,
                                       is_spherical_dataset: bool, seconds: int = 5) -> np.ndarray:

@@ -339,6 +339,15 @@ def test_get_nerf_from_the_reference_configs(oracle, golden_ckpt, tmp_path, caps
     assert dn.is_spherical_dataset
     np.testing.assert_allclose(dn.rot_mat_to_in_front_of_point_of_interest[:3, :3],
                                poses[dcfg[C.TRAINING][C.TEST_IMG_IDX]][:3, :3])
+    # by default the point of interest is ESTIMATED from all camera poses, as _init_dietnerf does (src/ExecutionRun.py:249-254)
+    auto = C.get_nerf(dcfg, near, far, images=images, camera_poses=poses, field_of_view=fov,
+                      embedder=_embedder(torch.float32, "cuda"))
+    want, spherical = N.estimate_point_of_interest_in_scene(poses)
+    assert spherical and auto.is_spherical_dataset
+    np.testing.assert_allclose(auto.point_of_interest_in_scene, want)
+    src = auto.sample_random_source_pose()
+    assert 0.7 - 1e-5 <= np.linalg.norm(src[:3, 3] - want) < 1.1 + 1e-5
+    auto.ctx.close()
     np.testing.assert_array_equal(dn.ctx.get_weights(0), N.glorot_blob(0))        # nothing saved: fresh Glorot networks
     _, d_img, d_pose = C.get_train_data(dcfg, images, poses)
     ds = N.prepare_ds(dn.batch_size_train, d_pose, d_img, fov, dn.ctx)

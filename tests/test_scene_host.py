@@ -1,0 +1,152 @@
+"""nerf_and_dietnerf_amd/scene.py against the reference's OWN tests: tests/test_UtilsCV.py of the reference holds 13 known-answer
+tests (plain numpy inputs, hand-computed expected values) for exactly these helpers -- the only tests it has.  Their inputs and
+expected values are restated here one for one (test names kept), followed by checks of what this package does differently
+(exhaustive instead of random consensus sets) and of the shipped dataset.  CPU only."""
+import os
+
+import numpy as np
+
+import nerf_and_dietnerf_amd as N
+from nerf_and_dietnerf_amd import scene as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sphere = N.get_sphere_matrix
+
+
+# ---- the reference's known-answer tests (tests/test_UtilsCV.py:15-187) ----------------------------------------------
+def test_normalize_vectors1():
+    assert np.allclose(S.normalize_vectors(np.asarray([1, 1])), np.asarray([0.7071, 0.7071]), atol=1e-4)
+
+
+def test_normalize_vectors2():
+    vecs = np.asarray([[1, 1], [1, 0], [0, 1]])
+    assert np.allclose(S.normalize_vectors(vecs), np.asarray([[0.7071, 0.7071], [1, 0], [0, 1]]), atol=1e-4)
+
+
+def test_estimate_3d_intersection():
+    dirs = np.asarray([[1, 1], [1, 1], [1, 1], [1, 0], [0, 1]])
+    location_on_points = np.asarray([[0, 0], [0, 0], [0, 0], [0, 1], [1, 0]])
+    dirs_and_t = np.stack([dirs, location_on_points], axis=1)
+    assert np.allclose(np.array([1, 1]), S.estimate_intersection_between_lines(dirs_and_t))
+
+
+def test_estimate_point_of_interest_in_scene1():
+    p, ok = S.estimate_point_of_interest_in_scene([sphere(1, 0, 0, 0), sphere(1, 0, 90, 0)])
+    assert ok and np.allclose(p, 0, atol=1e-6)
+
+
+def _shifted(args, shift):
+    m = np.array(sphere(*args), np.float64)
+    m[:3, 3] += shift
+    return m
+
+
+def test_estimate_point_of_interest_in_scene2():
+    views = [sphere(1, 0, 0, 0), sphere(1, 90, 0, 0), sphere(1, 0, 90, 0), sphere(1, 0, 0, 90), sphere(1, 0, 0, 90),
+             _shifted((1, 0, 90, 0), 1), _shifted((1, 0, 90, 0), -1)]                        # the last two: outliers
+    p, ok = S.estimate_point_of_interest_in_scene(views)
+    assert ok and np.allclose(p, 0, atol=1e-6)
+
+
+def test_estimate_point_of_interest_in_scene3():
+    views = [_shifted(a, 1) for a in ((1, 0, 0, 0), (1, 90, 0, 0), (1, 0, 90, 0), (1, 0, 0, 90), (1, 0, 0, 90))]
+    views += [sphere(1, 0, 90, 0), sphere(1, 0, 90, 0)]                                       # outliers
+    p, ok = S.estimate_point_of_interest_in_scene(views)
+    assert ok and np.allclose(p, 1, atol=1e-6)
+
+
+def test_estimate_point_of_interest_in_scene4():
+    p, ok = S.estimate_point_of_interest_in_scene([_shifted((1, 0, 0, 0), 1), _shifted((1, 90, 0, 0), -1),
+                                                    sphere(1, 0, 90, 0)])
+    assert not ok
+
+
+def test_get_rotation_quaternion_from_vec1_to_vec2():
+    v1 = np.asarray([1, 0, 0])
+    v2 = np.asarray([0, 1 / np.sqrt(2), 1 / np.sqrt(2)])                                      # at pi / 2 from v1
+    q = S.get_rotation_quaternion_from_vec1_to_vec2(v1, v2)
+    assert np.allclose(q, np.array([1 / np.sqrt(2), 0, -0.5, 0.5]))
+    assert np.allclose(v2, S.rotate_vec_with_quaternion(v1, q))
+
+
+def test_get_camera_dir_from_c2w():
+    assert np.allclose(np.asarray([0, 1, 0]), S.get_camera_dir_from_c2w(sphere(1, 90, 0, 0)), atol=1e-7)   # looking up +y
+
+
+def test_get_rotation_matrix_from_v1_to_v2_test1():
+    v1, v2 = S.get_camera_dir_from_c2w(sphere(1, 90, 0, 0)), S.get_camera_dir_from_c2w(sphere(1, 0, 0, 0))
+    rotation = S.get_rotation_matrix_from_v1_to_v2(v1, v2)
+    assert np.allclose(v2, rotation @ v1)
+    v3 = S.get_camera_dir_from_c2w(sphere(1, 0, 90, 0))
+    assert np.allclose(v3, rotation @ v3)                  # perpendicular to v1 and v2: on the axis, unaffected
+
+
+def test_get_rotation_matrix_from_v1_to_v2_test2():
+    v1 = np.asarray([1, 0, 0])
+    v2 = np.asarray([0, 1 / np.sqrt(2), 1 / np.sqrt(2)])
+    assert np.allclose(v2, S.get_rotation_matrix_from_v1_to_v2(v1, v2) @ v1)
+
+
+def _both_ways(a, b):
+    v1, v2 = S.get_camera_dir_from_c2w(sphere(*a)), S.get_camera_dir_from_c2w(sphere(*b))
+    assert np.allclose(v2, S.get_rotation_matrix_from_v1_to_v2(v1, v2) @ v1)
+    assert np.allclose(v2, S.rotate_vec_with_quaternion(v1, S.get_rotation_quaternion_from_vec1_to_vec2(v1, v2)))
+
+
+def test_get_rotation_matrix_from_v1_to_v2_test3():
+    _both_ways((1, 45, 0, 0), (1, 0, 0, 0))
+
+
+def test_get_rotation_matrix_from_v1_to_v2_test4():
+    _both_ways((1, 33, 133, 33), (1, 5, 243, 12))
+
+
+# ---- beyond the reference's tests -----------------------------------------------------------------------------------
+def test_degenerate_rotations():
+    """Equal directions: identity; opposite ones: a half turn about an axis orthogonal to them (also along x and y)."""
+    for v in ([1.0, 0, 0], [0, 1.0, 0], [0.3, -0.4, 0.5]):
+        v = np.asarray(v)
+        assert np.allclose(S.get_rotation_matrix_from_v1_to_v2(v, v), np.eye(3))
+        r = S.get_rotation_matrix_from_v1_to_v2(v, -v)
+        assert np.allclose(r @ v, -v) and np.allclose(r @ r.T, np.eye(3)) and abs(np.linalg.det(r) - 1) < 1e-12
+
+
+def test_least_squares_equals_the_stacked_system():
+    """The normal-equation solve is the reference's stacked lstsq (src/UtilsCV.py:349-355), skew and parallel lines included."""
+    rng = np.random.default_rng(0)
+    for lines in (rng.standard_normal((7, 2, 3)), np.stack([np.tile([[0.0, 0, 1]], (3, 1)), rng.standard_normal((3, 3))], 1)):
+        d = S.normalize_vectors(lines[:, 0])
+        proj = np.eye(3) - d[:, :, None] * d[:, None, :]
+        want = np.linalg.lstsq(np.concatenate(proj, 0), np.concatenate((proj @ lines[:, 1, :, None])[..., 0], 0), rcond=None)[0]
+        np.testing.assert_allclose(S.estimate_intersection_between_lines(lines), want, atol=1e-10)
+        got = S.get_distance_of_point_from_line(want, lines)
+        ref = np.array([(t - want) @ p @ (t - want) for p, t in zip(proj, lines[:, 1])])
+        np.testing.assert_allclose(got, ref, atol=1e-12)
+
+
+def test_sampled_consensus_agrees_with_the_exhaustive_one():
+    """More minimal sets than num_iter: random sets from the caller's generator -- same answer on a rig with a clear consensus."""
+    rng = np.random.default_rng(1)
+    views = [sphere(1.0, rng.uniform(-80, 0), rng.uniform(-180, 180), 0) for _ in range(40)]
+    views += [_shifted((1, rng.uniform(-80, 0), rng.uniform(-180, 180), 0), rng.uniform(0.5, 1, 3)) for _ in range(8)]
+    lines = np.asarray([[S.get_camera_dir_from_c2w(c), np.asarray(c, np.float64)[:3, 3]] for c in views])
+    p_all, in_all = S.ransac_get_estimation_for_intersection_point(lines)                      # 1128 pairs: all of them
+    p_rnd, in_rnd = S.ransac_get_estimation_for_intersection_point(lines, num_iter=200, rng=np.random.default_rng(5))
+    assert np.allclose(p_all, 0, atol=1e-6) and np.allclose(p_rnd, 0, atol=1e-6)
+    assert set(range(40)) <= set(in_all.tolist()) and set(in_all.tolist()) == set(in_rnd.tolist())
+
+
+def test_the_shipped_dataset_is_a_spherical_rig():
+    """The 71 spherified Alexander views (tests/golden/alexander50): the optical axes meet in one point (every axis passes
+    within 0.08 of it, 45 of 71 within the consensus tolerance), the cameras sit 0.8 - 1.2 away from it, and the rig counts as
+    spherical -- the branch DietNeRF's pose sampling (src/DietNeRF.py:246-253) and the video tours take for this scene."""
+    _, poses, *_ = N.get_data_from_colmap(os.path.join(HERE, "golden", "alexander50"))
+    p, spherical = S.estimate_point_of_interest_in_scene(poses)
+    assert spherical
+    lines = np.asarray([[S.get_camera_dir_from_c2w(c), np.asarray(c, np.float64)[:3, 3]] for c in poses])
+    miss = np.sqrt(np.maximum(S.get_distance_of_point_from_line(p, lines), 0))
+    assert miss.max() < 0.1 and (miss ** 2 < 0.001).sum() > 0.3 * len(poses)
+    radius = np.linalg.norm(poses[:, :3, 3] - p, axis=1)
+    assert 0.7 < radius.min() and radius.max() < 1.3
+    p2, _ = S.estimate_point_of_interest_in_scene(poses)              # all 2 485 pairs are tried: deterministic
+    np.testing.assert_array_equal(p, p2)
