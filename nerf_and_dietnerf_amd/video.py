@@ -148,10 +148,14 @@ def get_rotation_matrix_from_source_to_dest_mats(source_mat: np.ndarray, dest_ma
 # `estimated_intersection`) are arguments here.
 # ---------------------------------------------------------------------------------------------
 def get_l_to_r_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: int, fps_render_video: int,
-                                      is_spherical_dataset: bool, seconds: int = 5) -> np.ndarray:
+                                      is_spherical_dataset: Optional[bool] = None, seconds: int = 5) -> np.ndarray:
     """src/ExecutionRun.py:358-377: a 5 s slide along x.  Spherical datasets: the slide is taken in the test
-    view's frame (its rotation, position ``t_test - x``); otherwise it is placed at the average pose."""
+    view's frame (its rotation, position ``t_test - x``); otherwise it is placed at the average pose.
+    ``is_spherical_dataset=None``: decided by the scene analysis, as the reference does (:366)."""
     poses = np.asarray(camera_poses, np.float64)
+    if is_spherical_dataset is None:
+        from .scene import estimate_point_of_interest_in_scene
+        _, is_spherical_dataset = estimate_point_of_interest_in_scene(poses)
     mats = get_l_to_r_c2w_matrices(int(fps_render_video) * seconds).astype(np.float64)
     if is_spherical_dataset:
         mats[:, :3, 3] = poses[test_img_idx][:3, 3] - mats[:, :3, 3]
@@ -164,14 +168,18 @@ def get_l_to_r_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: in
 
 
 def get_sphere_c2w_matrices_to_render(camera_poses: np.ndarray, test_img_idx: int, fps_render_video: int,
-                                      is_spherical_dataset: bool, estimated_intersection=None,
+                                      is_spherical_dataset: Optional[bool] = None, estimated_intersection=None,
                                       blender_scale_and_distance: Optional[Tuple[float, float]] = None,
                                       seconds: int = 6) -> np.ndarray:
     """src/ExecutionRun.py:389-413: one turn about y and one about x on the unit sphere.  Spherical datasets:
     rotated so that the first pose has the test view's orientation and centred on the scene's point of interest;
     Blender left-to-right scenes (``blender_scale_and_distance`` = (c2w scale, average camera z before
-    recentring)): radius scaled and pushed back along the view axis."""
+    recentring)): radius scaled and pushed back along the view axis.  ``is_spherical_dataset=None``: both the branch
+    and the point of interest come from the scene analysis, as in the reference (:396)."""
     poses = np.asarray(camera_poses, np.float64)
+    if is_spherical_dataset is None:
+        from .scene import estimate_point_of_interest_in_scene
+        estimated_intersection, is_spherical_dataset = estimate_point_of_interest_in_scene(poses)
     mats = get_sphere_matrices(int(fps_render_video * seconds)).astype(np.float64)
     if is_spherical_dataset:
         rot = get_rotation_matrix_from_source_to_dest_mats(mats[0, :3, :3], poses[test_img_idx][:3, :3])

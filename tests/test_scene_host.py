@@ -150,3 +150,8 @@ def test_the_shipped_dataset_is_a_spherical_rig():
     assert 0.7 < radius.min() and radius.max() < 1.3
     p2, _ = S.estimate_point_of_interest_in_scene(poses)              # all 2 485 pairs are tried: deterministic
     np.testing.assert_array_equal(p, p2)
+    # the constant the video fixture holds (tests/golden/make_video_fixtures.py computed it independently, and the sphere-tour
+    # frames of the reference's own video are pinned with it, tests/test_video_pins.py)
+    fx = np.load(os.path.join(HERE, "golden", "alexander50_video_frames.npz"))
+    assert bool(fx["is_spherical_dataset"])
+    np.testing.assert_allclose(p, fx["estimated_intersection"], atol=1e-7)

@@ -54,6 +54,10 @@ def tours(frames, scene):
     t = {"l_to_r": N.get_l_to_r_c2w_matrices_to_render(scene["poses"], ti, fps, sph),
          "sphere": N.get_sphere_c2w_matrices_to_render(scene["poses"], ti, fps, sph, frames["estimated_intersection"]),
          "path": N.get_path_c2w_matrices_to_render(scene["poses"], frames["img_indices_for_path_video"], fps)}
+    # the product's own scene analysis (nerf_and_dietnerf_amd/scene.py; the builders' default) arrives at the same tours:
+    # the 234 stored reference frames these matrices are pinned against pin the analysis with them
+    np.testing.assert_allclose(N.get_sphere_c2w_matrices_to_render(scene["poses"], ti, fps), t["sphere"], atol=1e-6)
+    np.testing.assert_allclose(N.get_l_to_r_c2w_matrices_to_render(scene["poses"], ti, fps), t["l_to_r"], atol=1e-6)
     for name, m in t.items():
         assert len(m) == int(frames[name + "_n_frames"])       # 300 / 720 / 1320 frames, as the reference wrote
     return t
