@@ -20,7 +20,7 @@ from .scene import estimate_point_of_interest_in_scene
 from .config import get_nerf, get_num_of_batches, get_train_data, load_config
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
                        poses_avg, recenter_poses, spherify_poses)
-from .video import (get_c2w_matrices_between_2_c2w_with_stretch, get_path_c2w_matrices,
+from .video import (get_c2w_matrices_between_2_c2w, get_c2w_matrices_between_2_c2w_with_stretch, get_path_c2w_matrices,
                     get_l_to_r_c2w_matrices_to_render, get_path_c2w_matrices_to_render,
                     get_sphere_c2w_matrices_to_render,
                     get_rotation_matrix_from_source_to_dest_mats, interpolation_type_slerp_for_c2w,

@@ -115,6 +115,12 @@ def interpolation_type_slerp_for_c2w(c2w1: np.ndarray, c2w2: np.ndarray, alpha):
     return [one(a) for a in alpha] if alpha.shape != () else one(alpha)
 
 
+def get_c2w_matrices_between_2_c2w(c2w1, c2w2, n_renders: int = 16) -> list:
+    """``n_renders`` evenly spaced poses from c2w1 to c2w2 (src/UtilsCV.py:146-158): the camera path of the "rendering
+    between two dataset views" plot (src/ExecutionRun.py:534-537, 16 renders)."""
+    return interpolation_type_slerp_for_c2w(c2w1, c2w2, np.linspace(0, 1, n_renders))
+
+
 def get_c2w_matrices_between_2_c2w_with_stretch(c2w1, c2w2, n_renders: int, stretch_knob: float = 1) -> list:
     """``n_renders`` poses from c2w1 to c2w2, denser near c2w2 (the video slows down before it halts)."""
     alpha = np.linspace(0, 1, n_renders)

@@ -202,3 +202,20 @@ def test_collective_staging_rule():
     assert collective_device(True, "nccl", 3) is None
     assert collective_device(True, "gloo") == "cpu"                # one-GPU rehearsal
     assert collective_device(False, "gloo") is None
+
+
+def test_between_two_views_path():
+    """get_c2w_matrices_between_2_c2w (src/UtilsCV.py:146-158): 16 evenly spaced poses, the two views at the ends, rotations
+    throughout, the midpoint halfway in position and angle."""
+    import nerf_and_dietnerf_amd as N
+    a, b = N.get_sphere_matrix(1.0, -20, 10, 0), N.get_sphere_matrix(1.0, -50, 80, 0)
+    path = N.get_c2w_matrices_between_2_c2w(a, b)
+    assert len(path) == 16
+    np.testing.assert_allclose(path[0], a, atol=1e-6)
+    np.testing.assert_allclose(path[-1], b, atol=1e-6)
+    for m in path:
+        np.testing.assert_allclose(m[:3, :3] @ m[:3, :3].T, np.eye(3), atol=1e-5)
+    mid = N.get_c2w_matrices_between_2_c2w(a, b, 3)[1]
+    np.testing.assert_allclose(mid[:3, 3], 0.5 * (a[:3, 3] + b[:3, 3]), atol=1e-6)
+    ang = lambda r1, r2: np.arccos(np.clip((np.trace(r1.T @ r2) - 1) / 2, -1, 1))                     # noqa: E731
+    assert abs(ang(a[:3, :3], mid[:3, :3]) - ang(mid[:3, :3], b[:3, :3])) < 1e-5
