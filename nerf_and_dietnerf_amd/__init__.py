@@ -17,7 +17,8 @@ from .dataset import RayDataset, c2w_to_rays_prepare_ds, fit, prepare_ds
 from .dietnerf import DietNeRF
 from . import config, scene
 from .scene import estimate_point_of_interest_in_scene
-from .config import get_nerf, get_num_of_batches, get_train_data, load_config
+from .config import (get_nerf, get_num_of_batches, get_psnr_values, get_train_data, load_config,
+                     save_psnr_values)
 from .datasets import (get_data_from_blender, get_data_from_colmap, get_train_images_indices, load_llff_data,
                        poses_avg, recenter_poses, spherify_poses)
 from .video import (get_c2w_matrices_between_2_c2w, get_c2w_matrices_between_2_c2w_with_stretch, get_path_c2w_matrices,

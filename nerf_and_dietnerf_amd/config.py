@@ -6,6 +6,9 @@
     get_train_data            src/ExecutionRun.py:203-214,447-462   test view out, optional pics_indices_to_use_in_dataset
     get_nerf / _init_dietnerf src/ExecutionRun.py:216-262        type_of_model NeRF | DietNeRF, Adam(optimizer_lr), the
                                                                  mixed_float16 policy, weights of starting_epoch_number if saved
+    save_psnr_values / get_psnr_values  src/UtilsFiles.py:167-179,197-209   the per-epoch PSNR log beside the checkpoints
+                                                                 (saved_test_train_psnrs/psnrs_train_test_XXX.npy: a (2, epochs)
+                                                                 array, test view first)
 
 Not here (the reference's control plane): the task list, save-directory naming, plots, videos-to-disk,
 GCS sync.  The scene analysis ``_init_dietnerf`` runs on the camera poses (where do the cameras look, is the rig spherical:
@@ -119,3 +122,22 @@ def get_nerf(config: Dict, near_boundary: float, far_boundary: float, *, images=
         model.set_weights(glorot_blob(0, n_angles=na), glorot_blob(1, n_angles=na) if fine else None)
     model.compile(training[OPTIMIZER_LR], mixed_float16=policy == MIXED_FLOAT16)
     return model
+
+
+def save_psnr_values(psnrs_test_values, psnrs_train_values, filepath) -> None:
+    """src/UtilsFiles.py:167-179: the two per-epoch PSNR lists as one (2, epochs) ``.npy`` (test view first)."""
+    dirname = os.path.dirname(str(filepath))
+    if dirname and not os.path.exists(dirname):
+        os.makedirs(dirname)
+    np.save(str(filepath), (psnrs_test_values, psnrs_train_values))
+    print(f"Saved {filepath}!")
+
+
+def get_psnr_values(path_to_existing_psnr_values):
+    """src/UtilsFiles.py:197-209 -> (test PSNRs, train PSNRs) per epoch, or two empty lists when nothing is saved.
+    (Loaded without pickle: the file holds a plain float array.)"""
+    if path_to_existing_psnr_values and os.path.exists(path_to_existing_psnr_values):
+        psnrs_test_values, psnrs_train_values = np.load(str(path_to_existing_psnr_values), allow_pickle=False)
+        print(f"Loaded {path_to_existing_psnr_values}!")
+        return psnrs_test_values, psnrs_train_values
+    return [], []

@@ -74,3 +74,19 @@ def test_consistency_step_budget():
     """_init_dietnerf, src/ExecutionRun.py:241-247: 95 % of the remaining steps."""
     assert C.get_num_of_batches(2048, 5, 256, 256) == 160
     assert int(160 * (100 - 0) * N.DietNeRF.PERCENTAGE_OF_TRAIN_STEPS_WITH_CONSISTENCY_LOSS) == 15200
+
+
+def test_psnr_log_format(tmp_path):
+    """saved_test_train_psnrs/psnrs_train_test_XXX.npy (src/UtilsFiles.py:167-179,197-209): the reference's own log of the shipped
+    run (tests/golden/alexander50_recorded_psnrs.npy, copied data: (2, 95), test view first) reads back as two per-epoch lists,
+    and a log written here has the same layout."""
+    rec = os.path.join(HERE, "golden", "alexander50_recorded_psnrs.npy")
+    test, train = C.get_psnr_values(rec)
+    assert len(test) == len(train) == 95 and abs(test[-1] - 27.8338) < 1e-3 and abs(train[-1] - 32.4627) < 1e-3
+    out = tmp_path / "saved_test_train_psnrs" / "psnrs_train_test_003.npy"
+    C.save_psnr_values([20.0, 21.5, 22.0], [23.0, 24.5, 25.0], out)
+    a = np.load(str(out), allow_pickle=False)
+    assert a.shape == (2, 3) and a.dtype == np.float64
+    t2, r2 = C.get_psnr_values(out)
+    assert list(t2) == [20.0, 21.5, 22.0] and list(r2) == [23.0, 24.5, 25.0]
+    assert C.get_psnr_values(tmp_path / "missing.npy") == ([], [])
